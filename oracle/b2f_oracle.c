@@ -1,0 +1,683 @@
+/*
+ * b2f_oracle.c -- CPU ORACLE for the back2future computeFlow hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker, never the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The shipped path (back2future_amd/csrc, libb2f.so) never links,
+ * imports or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests
+ * or recorded outputs for this path, Torch7/LuaJIT are not
+ * installed, and the pretrained .t7 files are not in the tree.  What pins this
+ * restatement instead: (1) it follows the reference text line by line (cited
+ * below), (2) tests/test_oracle_vs_torch.py cross-checks every op against
+ * PyTorch-CPU as an independent implementation of the same THNN-lineage ops,
+ * (3) known-answer tests derived from the reference text (impulse test of
+ * CostVolMulti.lua:225-254, zero-flow warp = identity, border clamp).
+ *
+ * Conventions: all tensors fp32, layouts as in the reference (B x C x H x W,
+ * "BDHW"), except the sampler which is BHWD exactly like the module it restates.
+ * [3P] marks Torch7 package semantics (nn/cunn/cudnn/image) that are not
+ * readable under /root/reference and are restated from the published algorithm.
+ *
+ * Build: gcc -O3 -march=native -ffp-contract=off -fopenmp -shared -fPIC
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* transforms.lua:33-45  ColorNormalize: for every RGB triple c and colour i:
+ * img[3c+i] = (img[3c+i] + (-mean[i])) / std[i]   (add then div, on a clone).
+ * back2future.lua:33-36 gives mean/std.  Arithmetic is done in the tensor's
+ * own type; image.load yields float tensors, so fp32 here.                   */
+ORC_API void orc_color_normalize(float *img, int nch, int H, int W)
+{
+    static const float mean[3] = {0.485f, 0.456f, 0.406f};
+    static const float std_[3] = {0.229f, 0.224f, 0.225f};
+    const long hw = (long)H * W;
+    for (int c = 0; c < nch; ++c) {
+        const float m = -mean[c % 3], s = std_[c % 3];
+        float *p = img + (long)c * hw;
+        for (long i = 0; i < hw; ++i) p[i] = (p[i] + m) / s;
+    }
+}
+
+/* back2future.lua:54-67: round each side down to a multiple of 64. */
+ORC_API int orc_fine_size(int n) { return (n % 64 == 0) ? n : n - (n % 64); }
+
+/* ------------------------------------------------------------------------- */
+/* image.scale(src, W, H) default mode 'bilinear' [3P: torch/image
+ * generic/image.c Main_scaleBilinear / scaleLinear_rowcol].  Separable: the
+ * width pass writes a (C, Hs, Wd) temporary, then the height pass.  Per line:
+ * up-scaling = align-corners lerp with the last sample copied; down-scaling =
+ * running fractional box average; equal length = copy.  The intermediates
+ * (scale, fractions, accumulator) are C floats in that package.  Called at
+ * back2future.lua:71.                                                        */
+static void scale_line(const float *src, long sstride, long slen,
+                       float *dst, long dstride, long dlen)
+{
+    if (dlen > slen) {
+        const float scale = (float)(slen - 1) / (float)(dlen - 1);
+        if (slen == 1) {
+            for (long di = 0; di < dlen - 1; ++di) dst[di * dstride] = src[0];
+        } else {
+            for (long di = 0; di < dlen - 1; ++di) {
+                float si_f = di * scale;
+                long si_i = (long)si_f;
+                si_f -= si_i;
+                dst[di * dstride] = (1 - si_f) * src[si_i * sstride] +
+                                    si_f * src[(si_i + 1) * sstride];
+            }
+        }
+        dst[(dlen - 1) * dstride] = src[(slen - 1) * sstride];
+    } else if (dlen < slen) {
+        long si0_i = 0;
+        float si0_f = 0;
+        const float scale = (float)slen / (float)dlen;
+        for (long di = 0; di < dlen; ++di) {
+            float si1_f = (di + 1) * scale;
+            long si1_i = (long)si1_f;
+            si1_f -= si1_i;
+            float acc = (1 - si0_f) * src[si0_i * sstride];
+            float n = 1 - si0_f;
+            for (long si = si0_i + 1; si < si1_i; ++si) {
+                acc += src[si * sstride];
+                n += 1;
+            }
+            if (si1_i < slen) {
+                acc += si1_f * src[si1_i * sstride];
+                n += si1_f;
+            }
+            dst[di * dstride] = acc / n;
+            si0_i = si1_i;
+            si0_f = si1_f;
+        }
+    } else {
+        for (long i = 0; i < dlen; ++i) dst[i * dstride] = src[i * sstride];
+    }
+}
+
+ORC_API void orc_image_scale_bilinear(const float *src, int C, int Hs, int Ws,
+                                      float *dst, int Hd, int Wd)
+{
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)C * Hs * Wd);
+    for (int c = 0; c < C; ++c) {
+        for (int y = 0; y < Hs; ++y)
+            scale_line(src + ((long)c * Hs + y) * Ws, 1, Ws,
+                       tmp + ((long)c * Hs + y) * Wd, 1, Wd);
+        for (int x = 0; x < Wd; ++x)
+            scale_line(tmp + (long)c * Hs * Wd + x, Wd, Hs,
+                       dst + (long)c * Hd * Wd + x, Wd, Hd);
+    }
+    free(tmp);
+}
+
+/* image.scale(src, W, H, 'simple') [3P: Main_scaleSimple]: nearest with a
+ * float ratio, ii = (long)(i * (Ws/Wd)), clamped.  back2future.lua:82,89,91.
+ * Double in/out because computeFlow converts est to double first (:77,:87).  */
+ORC_API void orc_image_scale_simple_f64(const double *src, int C, int Hs, int Ws,
+                                        double *dst, int Hd, int Wd)
+{
+    const float scx = (float)Ws / (float)Wd, scy = (float)Hs / (float)Hd;
+    for (int c = 0; c < C; ++c)
+        for (int j = 0; j < Hd; ++j)
+            for (int i = 0; i < Wd; ++i) {
+                long ii = (long)((float)i * scx), jj = (long)((float)j * scy);
+                if (ii > Ws - 1) ii = Ws - 1;
+                if (jj > Hs - 1) jj = Hs - 1;
+                dst[((long)c * Hd + j) * Wd + i] = src[((long)c * Hs + jj) * Ws + ii];
+            }
+}
+
+ORC_API void orc_image_scale_simple_u8(const uint8_t *src, int C, int Hs, int Ws,
+                                       uint8_t *dst, int Hd, int Wd)
+{
+    const float scx = (float)Ws / (float)Wd, scy = (float)Hs / (float)Hd;
+    for (int c = 0; c < C; ++c)
+        for (int j = 0; j < Hd; ++j)
+            for (int i = 0; i < Wd; ++i) {
+                long ii = (long)((float)i * scx), jj = (long)((float)j * scy);
+                if (ii > Ws - 1) ii = Ws - 1;
+                if (jj > Hs - 1) jj = Hs - 1;
+                dst[((long)c * Hd + j) * Wd + i] = src[((long)c * Hs + jj) * Ws + ii];
+            }
+}
+
+/* ------------------------------------------------------------------------- */
+/* nn.SpatialConvolution(Ci,Co,3,3,s,s,1,1) [3P]: cross-correlation, zero pad 1,
+ * weight Co x Ci x 3 x 3, Hout = floor((H+2-3)/s)+1.  pwc.lua:60,62,78-83.
+ * Optional fused nn.LeakyReLU(0.2,true) (pwc.lua:61,63,78-82).               */
+ORC_API void orc_conv3x3(const float *x, int B, int Ci, int H, int W,
+                         const float *w, const float *bias, int Co, int stride,
+                         int leaky, float *y)
+{
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Co; ++co) {
+            float *yo = y + ((long)b * Co + co) * Ho * Wo;
+            for (long i = 0; i < (long)Ho * Wo; ++i) yo[i] = bias[co];
+            for (int ci = 0; ci < Ci; ++ci) {
+                const float *xi = x + ((long)b * Ci + ci) * H * W;
+                const float *wk = w + ((long)co * Ci + ci) * 9;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wk[ky * 3 + kx];
+                        /* valid output range: 0 <= s*Y+ky-1 < H */
+                        int Y0 = 0, Y1 = Ho, X0 = 0, X1 = Wo;
+                        while (Y0 < Ho && stride * Y0 + ky - 1 < 0) ++Y0;
+                        while (Y1 > Y0 && stride * (Y1 - 1) + ky - 1 >= H) --Y1;
+                        while (X0 < Wo && stride * X0 + kx - 1 < 0) ++X0;
+                        while (X1 > X0 && stride * (X1 - 1) + kx - 1 >= W) --X1;
+                        for (int Y = Y0; Y < Y1; ++Y) {
+                            const float *xr = xi + (long)(stride * Y + ky - 1) * W + (kx - 1);
+                            float *yr = yo + (long)Y * Wo;
+                            if (stride == 1)
+                                for (int X = X0; X < X1; ++X) yr[X] += wv * xr[X];
+                            else
+                                for (int X = X0; X < X1; ++X) yr[X] += wv * xr[stride * X];
+                        }
+                    }
+            }
+            if (leaky)
+                for (long i = 0; i < (long)Ho * Wo; ++i)
+                    yo[i] = yo[i] > 0 ? yo[i] : 0.2f * yo[i];
+        }
+}
+
+/* nn.SpatialAveragePooling(2,2,2,2) [3P]: mean of non-overlapping 2x2. pwc.lua:155 */
+ORC_API void orc_avgpool2(const float *x, int BC, int H, int W, float *y)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    for (int c = 0; c < BC; ++c)
+        for (int Y = 0; Y < Ho; ++Y)
+            for (int X = 0; X < Wo; ++X) {
+                const float *p = x + ((long)c * H + 2 * Y) * W + 2 * X;
+                y[((long)c * Ho + Y) * Wo + X] = (p[0] + p[1] + p[W] + p[W + 1]) / 4.0f;
+            }
+}
+
+/* nn.SpatialUpSamplingBilinear(2.0) [3P: THNN/THCUNN SpatialUpSamplingBilinear]:
+ * output 2h x 2w, align-corners ratios r = (in-1)/(out-1) in float;
+ * h1r = r*h2; h1 = (int)h1r; h1p = h1 < in-1; lambda = h1r - h1.  pwc.lua:360-381 */
+ORC_API void orc_upsample_bilinear2x(const float *x, int BC, int h, int w, float *y)
+{
+    const int H2 = 2 * h, W2 = 2 * w;
+    const float rh = (H2 > 1) ? (float)(h - 1) / (float)(H2 - 1) : 0.f;
+    const float rw = (W2 > 1) ? (float)(w - 1) / (float)(W2 - 1) : 0.f;
+    for (int c = 0; c < BC; ++c) {
+        const float *xi = x + (long)c * h * w;
+        float *yo = y + (long)c * H2 * W2;
+        for (int h2 = 0; h2 < H2; ++h2) {
+            const float h1r = rh * h2;
+            const int h1 = (int)h1r;
+            const int h1p = (h1 < h - 1) ? 1 : 0;
+            const float h1l = h1r - h1, h0l = 1.f - h1l;
+            for (int w2 = 0; w2 < W2; ++w2) {
+                const float w1r = rw * w2;
+                const int w1 = (int)w1r;
+                const int w1p = (w1 < w - 1) ? 1 : 0;
+                const float w1l = w1r - w1, w0l = 1.f - w1l;
+                const float *p = xi + (long)h1 * w + w1;
+                yo[(long)h2 * W2 + w2] =
+                    h0l * (w0l * p[0] + w1l * p[w1p]) +
+                    h1l * (w0l * p[(long)h1p * w] + w1l * p[(long)h1p * w + w1p]);
+            }
+        }
+    }
+}
+
+/* nn.SpatialUpSamplingNearest(2.0) [3P]: out[Y][X] = in[Y/2][X/2]. pwc.lua:312,319 */
+ORC_API void orc_upsample_nearest2x(const float *x, int BC, int h, int w, float *y)
+{
+    for (int c = 0; c < BC; ++c)
+        for (int Y = 0; Y < 2 * h; ++Y)
+            for (int X = 0; X < 2 * w; ++X)
+                y[((long)c * 2 * h + Y) * 2 * w + X] = x[((long)c * h + Y / 2) * w + X / 2];
+}
+
+/* nn.SpatialSoftMax [3P]: softmax over the channel dim at every pixel
+ * (max-subtracted form).  pwc.lua:308.                                       */
+ORC_API void orc_spatial_softmax(const float *x, int B, int C, int h, int w, float *y)
+{
+    const long hw = (long)h * w;
+    for (int b = 0; b < B; ++b)
+        for (long i = 0; i < hw; ++i) {
+            const float *p = x + (long)b * C * hw + i;
+            float *q = y + (long)b * C * hw + i;
+            float m = p[0];
+            for (int c = 1; c < C; ++c) m = p[c * hw] > m ? p[c * hw] : m;
+            float s = 0;
+            for (int c = 0; c < C; ++c) { q[c * hw] = expf(p[c * hw] - m); s += q[c * hw]; }
+            for (int c = 0; c < C; ++c) q[c * hw] = q[c * hw] / s;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* nn.CostVolMulti(win, fwd):updateOutput  --  models/CostVolMulti.lua:49-109,
+ * restated loop for loop: output zeroed (:59); q_x_ outer / q_y_ inner with the
+ * running channel index i (:66-67,:92); shifts scaled by (f-1) (:68-69);
+ * negated when fwd == false (:71-74); the 1-based slice ranges of :76-87
+ * (qx/px, qy/py) turned 0-based; cost = cmul(ref[qy,qx], frame[py,px]) summed
+ * over channels and ADDED into output[i] on the q-range (:89-90); final
+ * division by N*(frames-1) (:100).  frames[0] is the reference map.          */
+ORC_API void orc_costvol(const float *const *frames, int nframes, int B, int N,
+                         int h, int w, int win, int fwd, float *out)
+{
+    const int n = (win - 1) / 2;
+    const long hw = (long)h * w;
+    memset(out, 0, sizeof(float) * (size_t)B * win * win * hw);
+    const float *ref = frames[0];
+    for (int f = 1; f < nframes; ++f) {
+        const float *frame = frames[f];
+        int i = 0;
+        for (int q_x_ = -n; q_x_ <= n; ++q_x_)
+            for (int q_y_ = -n; q_y_ <= n; ++q_y_) {
+                int q_x = q_x_ * f, q_y = q_y_ * f; /* (f-1) in 1-based Lua */
+                if (!fwd) { q_x = -q_x; q_y = -q_y; }
+                /* 0-based inclusive-exclusive ranges */
+                int qx0 = q_x, qx1 = w, px0 = 0;
+                if (q_x < 0) { qx0 = 0; qx1 = w + q_x; px0 = -q_x; }
+                int qy0 = q_y, qy1 = h, py0 = 0;
+                if (q_y < 0) { qy0 = 0; qy1 = h + q_y; py0 = -q_y; }
+                if (qx1 > qx0 && qy1 > qy0) {
+#pragma omp parallel for schedule(static)
+                    for (int b = 0; b < B; ++b) {
+                        float *o = out + ((long)b * win * win + i) * hw;
+                        for (int k = 0; k < N; ++k) {
+                            const float *r = ref + ((long)b * N + k) * hw;
+                            const float *g = frame + ((long)b * N + k) * hw;
+                            for (int y = qy0; y < qy1; ++y) {
+                                const float *rr = r + (long)y * w;
+                                const float *gg = g + (long)(y - qy0 + py0) * w + (px0 - qx0);
+                                float *oo = o + (long)y * w;
+                                for (int x = qx0; x < qx1; ++x) oo[x] += rr[x] * gg[x];
+                            }
+                        }
+                    }
+                }
+                ++i;
+            }
+    }
+    const float div = (float)(N * (nframes - 1));
+    for (long j = 0; j < (long)B * win * win * hw; ++j) out[j] = out[j] / div;
+}
+
+/* ------------------------------------------------------------------------- */
+/* nn.BilinearSamplerBHWD:updateOutput, CUDA semantics --
+ * extras/stnbhwd/BilinearSamplerBHWD.cu:6-20 (getTopLeft: xcoord = x + xOut,
+ * clamp to [0, width-1], point = floor, weight = 1-(xcoord-point)), :69-70
+ * (grid channel 0 = x, 1 = y), :88-91 (a neighbour outside the image
+ * contributes 0), :101-104 (the four-term blend).  Output is sized by the grid
+ * (BilinearSamplerBHWD.lua:70).  NOT generic/BilinearSamplerBHWD.c (that is the
+ * normalized-grid CPU variant the models were not trained with). */
+ORC_API void orc_warp_bhwd(const float *img, const float *grid, int B, int ih, int iw,
+                           int C, int gh, int gw, float *out)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int yOut = 0; yOut < gh; ++yOut)
+            for (int xOut = 0; xOut < gw; ++xOut) {
+                const float *g = grid + (((long)b * gh + yOut) * gw + xOut) * 2;
+                float xc = g[0] + xOut;
+                if (xc < 0) xc = 0;
+                if (xc > (iw - 1)) xc = iw - 1;
+                const int xl = (int)floorf(xc);
+                const float xw = 1 - (xc - xl);
+                float yc = g[1] + yOut;
+                if (yc < 0) yc = 0;
+                if (yc > (ih - 1)) yc = ih - 1;
+                const int yt = (int)floorf(yc);
+                const float yw = 1 - (yc - yt);
+                const int xin0 = xl >= 0 && xl <= iw - 1, xin1 = xl + 1 >= 0 && xl + 1 <= iw - 1;
+                const int yin0 = yt >= 0 && yt <= ih - 1, yin1 = yt + 1 >= 0 && yt + 1 <= ih - 1;
+                const float *tl = img + (((long)b * ih + yt) * iw + xl) * C;
+                float *o = out + (((long)b * gh + yOut) * gw + xOut) * C;
+                for (int t = 0; t < C; ++t) {
+                    const float vtl = (xin0 && yin0) ? tl[t] : 0.f;
+                    const float vtr = (xin1 && yin0) ? tl[C + t] : 0.f;
+                    const float vbl = (xin0 && yin1) ? tl[(long)iw * C + t] : 0.f;
+                    const float vbr = (xin1 && yin1) ? tl[(long)iw * C + C + t] : 0.f;
+                    o[t] = xw * yw * vtl + (1 - xw) * yw * vtr + xw * (1 - yw) * vbl +
+                           (1 - xw) * (1 - yw) * vbr;
+                }
+            }
+}
+
+/* warpingUnit(I, F) -- pwc.lua:68-73: Transpose BDHW->BHWD on both inputs,
+ * sampler, Transpose back.  F has already been through nn.MulConstant(k)
+ * (pwc.lua:404,443), which is folded in here as `k` applied in fp32.         */
+static void warping_unit(const float *I, const float *F, float k, int B, int C,
+                         int h, int w, float *out)
+{
+    const long hw = (long)h * w;
+    float *ib = (float *)malloc(sizeof(float) * (size_t)B * hw * C);
+    float *fb = (float *)malloc(sizeof(float) * (size_t)B * hw * 2);
+    float *ob = (float *)malloc(sizeof(float) * (size_t)B * hw * C);
+    for (int b = 0; b < B; ++b)
+        for (long i = 0; i < hw; ++i) {
+            for (int c = 0; c < C; ++c) ib[((long)b * hw + i) * C + c] = I[((long)b * C + c) * hw + i];
+            for (int c = 0; c < 2; ++c) fb[((long)b * hw + i) * 2 + c] = F[((long)b * 2 + c) * hw + i] * k;
+        }
+    orc_warp_bhwd(ib, fb, B, h, w, C, h, w, ob);
+    for (int b = 0; b < B; ++b)
+        for (long i = 0; i < hw; ++i)
+            for (int c = 0; c < C; ++c) out[((long)b * C + c) * hw + i] = ob[((long)b * hw + i) * C + c];
+    free(ib); free(fb); free(ob);
+}
+
+ORC_API void orc_warping_unit(const float *I, const float *F, float k, int B, int C,
+                              int h, int w, float *out)
+{
+    warping_unit(I, F, k, B, C, h, w, out);
+}
+
+/* ------------------------------------------------------------------------- */
+/* The shipped architecture: createModelMulti(opt) of models/pwc.lua:87-508 with
+ * opts.lua:83-98 (frames 3, levels 7, residual 0, occ_input 0, rescale_flow 0,
+ * flownet_factor 20, pwc_ws 9, pwc_skip 2, pwc_siamese 1, pwc_sum_cvs false,
+ * two_frame 0), past_flow = false ("Ours-Hard") / true ("Ours-Soft-*").
+ *
+ * Canonical flat weight order used by this repo (oracle and product agree on
+ * it): feature units l = 2..7 {conv1.w, conv1.b, conv2.w,
+ * conv2.b}; then for l = 7..3: occ decoder, flow decoder, [past-flow decoder],
+ * each 6 x {w, b}; every w in Torch layout Co x Ci x 3 x 3.                   */
+enum { LEVELS = 7, L_ST = 3, WIN = 9 };
+static const int FEAT[8] = {0, 3, 16, 32, 64, 96, 128, 192}; /* featMaps, pwc.lua:29,89 */
+static const int DEC[7] = {0, 128, 128, 96, 64, 32, 2};       /* decoder(), pwc.lua:76-85 */
+
+static long conv_params(int ci, int co) { return (long)co * ci * 9 + co; }
+static long decoder_params(int n)
+{
+    long s = 0;
+    int ci = n;
+    for (int i = 1; i <= 6; ++i) { s += conv_params(ci, DEC[i]); ci = DEC[i]; }
+    return s;
+}
+static int occ_in_ch(int l) { return 2 * WIN * WIN + FEAT[l] + (l != LEVELS ? 2 : 0); }   /* pwc.lua:288-304 */
+static int flow_in_ch(int l) { return l == LEVELS ? 2 * WIN * WIN : 2 * WIN * WIN + FEAT[l] + 2; } /* :325-337 */
+
+ORC_API long orc_param_count(int past_flow)
+{
+    long s = 0;
+    for (int l = 2; l <= LEVELS; ++l) s += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
+    for (int l = LEVELS; l >= L_ST; --l) {
+        s += decoder_params(occ_in_ch(l)) + decoder_params(flow_in_ch(l));
+        if (past_flow) s += decoder_params(flow_in_ch(l));
+    }
+    return s;
+}
+
+static float *falloc(long n) { return (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); }
+
+/* convUnit -- pwc.lua:58-65 */
+static const float *conv_unit(const float *x, int B, int ci, int co, int H, int W,
+                              const float *p, float *tmp, float *y)
+{
+    const float *w1 = p, *b1 = w1 + (long)co * ci * 9, *w2 = b1 + co, *b2 = w2 + (long)co * co * 9;
+    orc_conv3x3(x, B, ci, H, W, w1, b1, co, 2, 1, tmp);
+    orc_conv3x3(tmp, B, co, H / 2, W / 2, w2, b2, co, 1, 1, y);
+    return b2 + co;
+}
+
+/* decoder(n) -- pwc.lua:76-85: six 3x3 convs, LeakyReLU(0.2) after the first five */
+static const float *run_decoder(const float *x, int B, int n, int h, int w, const float *p, float *y)
+{
+    const long hw = (long)h * w;
+    float *a = falloc((long)B * 128 * hw), *b = falloc((long)B * 128 * hw);
+    const float *in = x;
+    int ci = n;
+    for (int i = 1; i <= 6; ++i) {
+        const float *wt = p, *bs = p + (long)DEC[i] * ci * 9;
+        float *o = (i == 6) ? y : ((i & 1) ? a : b);
+        orc_conv3x3(in, B, ci, h, w, wt, bs, DEC[i], 1, i < 6, o);
+        p = bs + DEC[i];
+        in = o;
+        ci = DEC[i];
+    }
+    free(a); free(b);
+    return p;
+}
+
+/* nn.JoinTable(2): channel concat in table order (pwc.lua:267,308,334,337) */
+static void join_channels(float *dst, int B, long hw, int nsrc, const float *const *src, const int *ch)
+{
+    int ct = 0;
+    for (int s = 0; s < nsrc; ++s) ct += ch[s];
+    for (int b = 0; b < B; ++b) {
+        int off = 0;
+        for (int s = 0; s < nsrc; ++s) {
+            memcpy(dst + ((long)b * ct + off) * hw, src[s] + (long)b * ch[s] * hw, sizeof(float) * (size_t)ch[s] * hw);
+            off += ch[s];
+        }
+    }
+}
+
+/* model:forward(imgs) for the shipped graph.  x: B x 9 x H x W (normalized),
+ * H, W multiples of 64.  outs: n_outputs tensors in the order of the output
+ * table, pwc.lua:459-489 (finest level first: skip_ufs[l], [skip_ubfs[l]],
+ * skip_occs[l], iws[1][l], iws[3][l] for l = 3..7); caller allocates:
+ * flow/occ tensors B x 2 x 4h_l x 4w_l, warped images B x 3 x 4h_l x 4w_l.
+ * Returns the number of output tensors (20 Hard / 25 Soft).                  */
+ORC_API int orc_pwc_forward(const float *x, int B, int H, int W, const float *params,
+                            int past_flow, float **outs)
+{
+    const int frames = 3, ref = 2;
+    float *Is[4] = {0}, *ds[4][6] = {{0}}, *cs[4][8] = {{0}}, *ws[4][8] = {{0}};
+    float *fs[8] = {0}, *bfs[8] = {0}, *ufs[8] = {0}, *ubfs[8] = {0};
+    float *skip_ufs[8] = {0}, *skip_ubfs[8] = {0}, *occs[8] = {0}, *skip_occs[8] = {0};
+    float *iws[4][8] = {{0}};
+    int hh[8], wl[8];
+    for (int l = 1; l <= LEVELS; ++l) { hh[l] = H >> (l - 1); wl[l] = W >> (l - 1); }
+    const long HW = (long)H * W;
+
+    /* nn.Narrow(2, a, 3) -- pwc.lua:139-145 */
+    for (int f = 1; f <= frames; ++f) {
+        Is[f] = falloc((long)B * 3 * HW);
+        for (int b = 0; b < B; ++b)
+            memcpy(Is[f] + (long)b * 3 * HW, x + ((long)b * 9 + 3 * (f - 1)) * HW, sizeof(float) * 3 * HW);
+    }
+    /* image pyramid for the warped-image outputs -- pwc.lua:148-158 */
+    for (int f = 1; f <= frames; ++f) {
+        if (f == ref) continue;
+        ds[f][1] = Is[f];
+        for (int k = 2; k <= LEVELS - L_ST + 1; ++k) {
+            ds[f][k] = falloc((long)B * 3 * (H >> (k - 1)) * (W >> (k - 1)));
+            orc_avgpool2(ds[f][k - 1], B * 3, H >> (k - 2), W >> (k - 2), ds[f][k]);
+        }
+    }
+    /* siamese feature pyramid, shared weights -- pwc.lua:169-211 */
+    const float *p = params, *pdec;
+    {
+        const float *pn = p;
+        for (int f = 1; f <= frames; ++f) {
+            cs[f][1] = Is[f];
+            pn = p;
+            for (int l = 2; l <= LEVELS; ++l) {
+                float *tmp = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
+                cs[f][l] = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
+                pn = conv_unit(cs[f][l - 1], B, FEAT[l - 1], FEAT[l], hh[l - 1], wl[l - 1], pn, tmp, cs[f][l]);
+                free(tmp);
+            }
+        }
+        pdec = pn;
+    }
+    p = pdec;
+
+    for (int l = LEVELS; l >= L_ST; --l) { /* pwc.lua:237 */
+        const int h = hh[l], w = wl[l], C = FEAT[l];
+        const long hw = (long)h * w;
+        float **input_f3 = (l == LEVELS) ? &cs[3][l] : &ws[3][l]; /* :238-244 */
+        float **input_f1 = (l == LEVELS) ? &cs[1][l] : &ws[1][l];
+        /* cost volumes -- :246-263 */
+        float *cv_fwd = falloc((long)B * 81 * hw), *cv_bwd = falloc((long)B * 81 * hw);
+        { const float *fr[2] = {cs[ref][l], *input_f3}; orc_costvol(fr, 2, B, C, h, w, WIN, 1, cv_fwd); }
+        { const float *fr[2] = {cs[ref][l], *input_f1}; orc_costvol(fr, 2, B, C, h, w, WIN, 0, cv_bwd); }
+        float *cv = falloc((long)B * 162 * hw); /* JoinTable :267 */
+        { const float *s[2] = {cv_fwd, cv_bwd}; int c[2] = {81, 81}; join_channels(cv, B, hw, 2, s, c); }
+        free(cv_fwd); free(cv_bwd);
+
+        /* occlusion decoder + SpatialSoftMax -- :288-308 */
+        {
+            const int n = occ_in_ch(l);
+            float *din = falloc((long)B * n * hw), *dout = falloc((long)B * 2 * hw);
+            const float *s[3] = {cv, cs[ref][l], (l != LEVELS) ? ufs[l + 1] : 0};
+            int c[3] = {162, C, 2};
+            join_channels(din, B, hw, (l != LEVELS) ? 3 : 2, s, c);
+            p = run_decoder(din, B, n, h, w, p, dout);
+            occs[l] = falloc((long)B * 2 * hw);
+            orc_spatial_softmax(dout, B, 2, h, w, occs[l]);
+            free(din); free(dout);
+            /* uoccs = nearest x2; skip_occs = one more nearest x2 (l_st-1 = 2) -- :311-321 */
+            float *uo = falloc((long)B * 2 * hw * 4);
+            orc_upsample_nearest2x(occs[l], B * 2, h, w, uo);
+            skip_occs[l] = falloc((long)B * 2 * hw * 16);
+            orc_upsample_nearest2x(uo, B * 2, 2 * h, 2 * w, skip_occs[l]);
+            free(uo);
+        }
+        /* flow decoders -- :325-352 (residual = 0) */
+        {
+            const int n = flow_in_ch(l);
+            fs[l] = falloc((long)B * 2 * hw);
+            if (l == LEVELS) {
+                p = run_decoder(cv, B, n, h, w, p, fs[l]);
+                if (past_flow) { bfs[l] = falloc((long)B * 2 * hw); p = run_decoder(cv, B, n, h, w, p, bfs[l]); }
+            } else {
+                float *din = falloc((long)B * n * hw);
+                const float *s[3] = {cv, cs[ref][l], ufs[l + 1]};
+                int c[3] = {162, C, 2};
+                join_channels(din, B, hw, 3, s, c);
+                p = run_decoder(din, B, n, h, w, p, fs[l]);
+                if (past_flow) {
+                    s[2] = ubfs[l + 1];
+                    join_channels(din, B, hw, 3, s, c);
+                    bfs[l] = falloc((long)B * 2 * hw);
+                    p = run_decoder(din, B, n, h, w, p, bfs[l]);
+                }
+                free(din);
+            }
+        }
+        free(cv);
+        /* upsampling -- :359-390: ufs = bilinear x2, skip_ufs = a second bilinear x2 */
+        ufs[l] = falloc((long)B * 2 * hw * 4);
+        orc_upsample_bilinear2x(fs[l], B * 2, h, w, ufs[l]);
+        skip_ufs[l] = falloc((long)B * 2 * hw * 16);
+        orc_upsample_bilinear2x(ufs[l], B * 2, 2 * h, 2 * w, skip_ufs[l]);
+        if (past_flow) {
+            ubfs[l] = falloc((long)B * 2 * hw * 4);
+            orc_upsample_bilinear2x(bfs[l], B * 2, h, w, ubfs[l]);
+            skip_ubfs[l] = falloc((long)B * 2 * hw * 16);
+            orc_upsample_bilinear2x(ubfs[l], B * 2, 2 * h, 2 * w, skip_ubfs[l]);
+        }
+        /* warps -- :393-446 */
+        for (int f = 1; f <= frames; ++f) {
+            if (f == ref) continue;
+            if (l > L_ST) { /* :395-408: MulConstant(20*(f-ref)/2^(l-2)) */
+                const float k = (float)(20.0 * (f - ref) / pow(2, l - 2));
+                ws[f][l - 1] = falloc((long)B * FEAT[l - 1] * hw * 4);
+                warping_unit(cs[f][l - 1], ufs[l], k, B, FEAT[l - 1], 2 * h, 2 * w, ws[f][l - 1]);
+            }
+            /* :422-446: image warp with skip_u(b)fs, MulConstant(20*(f-ref)/2^(l-l_st)) */
+            const float *tmp = (past_flow && f < ref) ? skip_ubfs[l] : skip_ufs[l];
+            const float k2 = (float)(20.0 * (f - ref) / pow(2, l - L_ST));
+            iws[f][l] = falloc((long)B * 3 * hw * 16);
+            warping_unit(ds[f][l - L_ST + 1], tmp, k2, B, 3, 4 * h, 4 * w, iws[f][l]);
+        }
+    }
+
+    /* output table -- pwc.lua:459-489 */
+    int no = 0;
+    for (int l = L_ST; l <= LEVELS; ++l) {
+        const long n2 = (long)B * 2 * hh[l] * wl[l] * 16, n3 = (long)B * 3 * hh[l] * wl[l] * 16;
+        memcpy(outs[no++], skip_ufs[l], sizeof(float) * n2);
+        if (past_flow) memcpy(outs[no++], skip_ubfs[l], sizeof(float) * n2);
+        memcpy(outs[no++], skip_occs[l], sizeof(float) * n2);
+        memcpy(outs[no++], iws[1][l], sizeof(float) * n3);
+        memcpy(outs[no++], iws[3][l], sizeof(float) * n3);
+    }
+
+    for (int f = 1; f <= frames; ++f) {
+        free(Is[f]);
+        for (int k = 2; k <= 5; ++k) free(ds[f][k]);
+        for (int l = 2; l <= LEVELS; ++l) { free(cs[f][l]); free(ws[f][l]); free(iws[f][l]); }
+    }
+    for (int l = 0; l < 8; ++l) {
+        free(fs[l]); free(bfs[l]); free(ufs[l]); free(ubfs[l]); free(skip_ufs[l]);
+        free(skip_ubfs[l]); free(occs[l]); free(skip_occs[l]);
+    }
+    return no;
+}
+
+/* Sizes of the output table entries (channels and spatial size), same order. */
+ORC_API int orc_pwc_output_shapes(int H, int W, int past_flow, int *ch, int *oh, int *ow)
+{
+    int no = 0;
+    for (int l = L_ST; l <= LEVELS; ++l) {
+        const int h4 = (H >> (l - 1)) * 4, w4 = (W >> (l - 1)) * 4;
+        const int per = past_flow ? 5 : 4;
+        for (int j = 0; j < per; ++j) {
+            const int is_img = (j >= per - 2);
+            ch[no] = is_img ? 3 : 2; oh[no] = h4; ow[no] = w4; ++no;
+        }
+    }
+    return no;
+}
+
+/* ------------------------------------------------------------------------- */
+/* computeFlow(im1, im2, im3) -- back2future.lua:47-95.  im*: 3 x H0 x W0 planar
+ * floats in [0,1].  Outputs: flow 2 x H0 x W0 double (raw network flow, NOT
+ * multiplied by 20: SURVEY s0.4), fwd_occ / bwd_occ 1 x H0 x W0 bytes.  est[3]
+ * is read by fixed position (:87), i.e. the occlusion map only for Soft
+ * models; for a Hard model est[3] = warped image 1 and its channels 2 / 1 are
+ * thresholded, exactly as the reference would.  occ_prob (optional, may be
+ * NULL) receives est[3][0..1] at net resolution before thresholding.         */
+ORC_API int orc_compute_flow(const float *im1, const float *im2, const float *im3,
+                             int H0, int W0, const float *params, int past_flow,
+                             double *flow, uint8_t *fwd_occ, uint8_t *bwd_occ,
+                             float *flow_net, float *occ_net)
+{
+    const long hw0 = (long)H0 * W0;
+    float *imgs = falloc(9 * hw0); /* torch.cat :48 */
+    memcpy(imgs, im1, sizeof(float) * 3 * hw0);
+    memcpy(imgs + 3 * hw0, im2, sizeof(float) * 3 * hw0);
+    memcpy(imgs + 6 * hw0, im3, sizeof(float) * 3 * hw0);
+    orc_color_normalize(imgs, 9, H0, W0); /* :49 */
+    const int fw = orc_fine_size(W0), fh = orc_fine_size(H0); /* :54-67 */
+    if (fw <= 0 || fh <= 0) { free(imgs); return -1; }
+    const long hw = (long)fh * fw;
+    float *net_in = falloc(9 * hw);
+    orc_image_scale_bilinear(imgs, 9, H0, W0, net_in, fh, fw); /* :71 */
+    free(imgs);
+
+    int ch[32], oh[32], ow[32];
+    const int no = orc_pwc_output_shapes(fh, fw, past_flow, ch, oh, ow);
+    float *outs[32];
+    for (int i = 0; i < no; ++i) outs[i] = falloc((long)ch[i] * oh[i] * ow[i]);
+    orc_pwc_forward(net_in, 1, fh, fw, params, past_flow, outs); /* :73-74 */
+    free(net_in);
+
+    /* :77-84 */
+    double *fd = (double *)malloc(sizeof(double) * 2 * hw);
+    for (long i = 0; i < 2 * hw; ++i) fd[i] = (double)outs[0][i];
+    if (flow_net) memcpy(flow_net, outs[0], sizeof(float) * 2 * hw);
+    const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;
+    orc_image_scale_simple_f64(fd, 2, fh, fw, flow, H0, W0);
+    for (long i = 0; i < hw0; ++i) { flow[hw0 + i] *= sc_h; }
+    for (long i = 0; i < hw0; ++i) { flow[i] *= sc_w; }
+    free(fd);
+    /* :87-91 : est[3], channel 2 -> fwd, channel 1 -> bwd, threshold 0.6666 in double */
+    const float *occ = outs[2];
+    if (occ_net) memcpy(occ_net, occ, sizeof(float) * 2 * hw);
+    uint8_t *m = (uint8_t *)malloc((size_t)hw);
+    for (long i = 0; i < hw; ++i) m[i] = ((double)occ[hw + i] >= 0.6666) ? 1 : 0;
+    orc_image_scale_simple_u8(m, 1, fh, fw, fwd_occ, H0, W0);
+    for (long i = 0; i < hw; ++i) m[i] = ((double)occ[i] >= 0.6666) ? 1 : 0;
+    orc_image_scale_simple_u8(m, 1, fh, fw, bwd_occ, H0, W0);
+    free(m);
+    for (int i = 0; i < no; ++i) free(outs[i]);
+    return 0;
+}

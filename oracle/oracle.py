@@ -1,0 +1,187 @@
+"""ctypes wrapper around oracle/libb2f_oracle.so (the CPU oracle).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under back2future_amd/ imports this.
+Layouts follow the reference modules (BDHW everywhere, BHWD for the sampler).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libb2f_oracle.so")
+_lib = None
+
+FEAT = [0, 3, 16, 32, 64, 96, 128, 192]
+DEC = [128, 128, 96, 64, 32, 2]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "b2f_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libb2f_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_param_count.restype = C.c_long
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def param_count(past_flow):
+    return int(lib().orc_param_count(int(bool(past_flow))))
+
+
+def color_normalize(img):
+    a = np.array(img, dtype=np.float32, order="C", copy=True)
+    c, h, w = a.shape
+    lib().orc_color_normalize(a.ctypes.data_as(C.POINTER(C.c_float)), c, h, w)
+    return a
+
+
+def image_scale_bilinear(src, Hd, Wd):
+    s, sp = _f(src)
+    c, hs, ws = s.shape
+    d = np.empty((c, Hd, Wd), np.float32)
+    lib().orc_image_scale_bilinear(sp, c, hs, ws, d.ctypes.data_as(C.POINTER(C.c_float)), Hd, Wd)
+    return d
+
+
+def image_scale_simple(src, Hd, Wd):
+    src = np.ascontiguousarray(src)
+    c, hs, ws = src.shape
+    d = np.empty((c, Hd, Wd), src.dtype)
+    if src.dtype == np.float64:
+        lib().orc_image_scale_simple_f64(src.ctypes.data_as(C.c_void_p), c, hs, ws,
+                                         d.ctypes.data_as(C.c_void_p), Hd, Wd)
+    elif src.dtype == np.uint8:
+        lib().orc_image_scale_simple_u8(src.ctypes.data_as(C.c_void_p), c, hs, ws,
+                                        d.ctypes.data_as(C.c_void_p), Hd, Wd)
+    else:
+        raise TypeError(src.dtype)
+    return d
+
+
+def conv3x3(x, w, b, stride=1, leaky=False):
+    x, xp = _f(x); w, wp = _f(w); b, bp = _f(b)
+    B, ci, H, W = x.shape
+    co = w.shape[0]
+    assert w.shape == (co, ci, 3, 3)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = np.empty((B, co, Ho, Wo), np.float32)
+    lib().orc_conv3x3(xp, B, ci, H, W, wp, bp, co, stride, int(leaky),
+                      y.ctypes.data_as(C.POINTER(C.c_float)))
+    return y
+
+
+def _bc(fn, x, scale):
+    x, xp = _f(x)
+    B, c, h, w = x.shape
+    y = np.empty((B, c, int(h * scale), int(w * scale)), np.float32)
+    fn(xp, B * c, h, w, y.ctypes.data_as(C.POINTER(C.c_float)))
+    return y
+
+
+def avgpool2(x):
+    return _bc(lib().orc_avgpool2, x, 0.5)
+
+
+def upsample_bilinear2x(x):
+    return _bc(lib().orc_upsample_bilinear2x, x, 2)
+
+
+def upsample_nearest2x(x):
+    return _bc(lib().orc_upsample_nearest2x, x, 2)
+
+
+def spatial_softmax(x):
+    x, xp = _f(x)
+    B, c, h, w = x.shape
+    y = np.empty_like(x)
+    lib().orc_spatial_softmax(xp, B, c, h, w, y.ctypes.data_as(C.POINTER(C.c_float)))
+    return y
+
+
+def costvol(frames, win=9, fwd=True):
+    """frames: list of B x N x h x w maps, frames[0] = reference."""
+    arrs = [np.ascontiguousarray(f, dtype=np.float32) for f in frames]
+    B, N, h, w = arrs[0].shape
+    ptrs = (C.POINTER(C.c_float) * len(arrs))(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
+    out = np.empty((B, win * win, h, w), np.float32)
+    lib().orc_costvol(ptrs, len(arrs), B, N, h, w, win, int(bool(fwd)),
+                      out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def warp_bhwd(img, grid):
+    """img B x ih x iw x C, grid B x gh x gw x 2 (x first) -> B x gh x gw x C."""
+    img, ip = _f(img); grid, gp = _f(grid)
+    B, ih, iw, c = img.shape
+    _, gh, gw, two = grid.shape
+    assert two == 2 and grid.shape[0] == B
+    out = np.empty((B, gh, gw, c), np.float32)
+    lib().orc_warp_bhwd(ip, gp, B, ih, iw, c, gh, gw, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def warping_unit(I, F, k):
+    I, ip = _f(I); F, fp = _f(F)
+    B, c, h, w = I.shape
+    out = np.empty_like(I)
+    lib().orc_warping_unit(ip, fp, C.c_float(k), B, c, h, w, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def output_shapes(H, W, past_flow):
+    ch = (C.c_int * 32)(); oh = (C.c_int * 32)(); ow = (C.c_int * 32)()
+    n = lib().orc_pwc_output_shapes(H, W, int(bool(past_flow)), ch, oh, ow)
+    return [(ch[i], oh[i], ow[i]) for i in range(n)]
+
+
+def pwc_forward(x, params, past_flow):
+    """x: B x 9 x H x W normalized; returns the full output table (list)."""
+    x, xp = _f(x); params, pp = _f(params)
+    assert params.size == param_count(past_flow), (params.size, param_count(past_flow))
+    B, nine, H, W = x.shape
+    assert nine == 9 and H % 64 == 0 and W % 64 == 0
+    shapes = output_shapes(H, W, past_flow)
+    outs = [np.empty((B, c, h, w), np.float32) for (c, h, w) in shapes]
+    ptrs = (C.POINTER(C.c_float) * len(outs))(*[o.ctypes.data_as(C.POINTER(C.c_float)) for o in outs])
+    n = lib().orc_pwc_forward(xp, B, H, W, pp, int(bool(past_flow)), ptrs)
+    assert n == len(outs)
+    return outs
+
+
+def compute_flow(im1, im2, im3, params, past_flow, want_net=False):
+    im1, p1 = _f(im1); im2, p2 = _f(im2); im3, p3 = _f(im3)
+    params, pp = _f(params)
+    assert params.size == param_count(past_flow)
+    _, H0, W0 = im1.shape
+    flow = np.empty((2, H0, W0), np.float64)
+    fo = np.empty((1, H0, W0), np.uint8)
+    bo = np.empty((1, H0, W0), np.uint8)
+    fh, fw = H0 - H0 % 64, W0 - W0 % 64
+    fn = np.empty((2, fh, fw), np.float32)
+    on = np.empty((2, fh, fw), np.float32)
+    rc = lib().orc_compute_flow(p1, p2, p3, H0, W0, pp, int(bool(past_flow)),
+                                flow.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p),
+                                bo.ctypes.data_as(C.c_void_p),
+                                fn.ctypes.data_as(C.POINTER(C.c_float)),
+                                on.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise RuntimeError("orc_compute_flow failed: %d" % rc)
+    if want_net:
+        return flow, fo, bo, fn, on
+    return flow, fo, bo
