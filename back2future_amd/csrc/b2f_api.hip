@@ -1,0 +1,892 @@
+// C-ABI layer of libb2f.so (include/b2f.h): context, weight packing, workspace, the
+// computeFlow pipeline (back2future.lua:47-95 around models/pwc.lua's graph), hipGraph
+// capture, per-kernel HIP-event profiling, and op-level entry points for parity tests.
+#include "../../include/b2f.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "b2f_host.h"
+#include "b2f_internal.h"
+
+using namespace b2f;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m)
+{
+    g_err = m;
+    return 1;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+#define CHK(expr)                         \
+    do {                                  \
+        int rc_ = (expr);                 \
+        if (rc_ != 0) return rc_;         \
+    } while (0)
+
+namespace {
+
+struct PackedConv {
+    int nseg = 1;
+    int chunks[2] = {0, 0};
+    int cout = 0, nt = 1, nblk = 1;
+    size_t w_off = 0, b_off = 0;   // float offsets into wpk_dev
+};
+
+struct ProfEvent {
+    int name;
+    hipEvent_t a, b;
+};
+
+struct GraphKey {
+    const void *in;
+    float *flow, *occ, *est3;
+    int kind, B, H, W;
+    bool operator<(const GraphKey &o) const
+    {
+        return std::tie(in, flow, occ, est3, kind, B, H, W) < std::tie(o.in, o.flow, o.occ, o.est3, o.kind, o.B, o.H, o.W);
+    }
+};
+
+}  // namespace
+
+struct b2f_ctx {
+    int device = 0;
+    bool past_flow = false;
+    long long nparams = 0;
+    hipStream_t stream = nullptr;
+    std::vector<ConvDesc> lay;
+    std::vector<PackedConv> packed;
+    float *w_dev = nullptr;     // flat canonical weights
+    float *wpk_dev = nullptr;   // packed kernel-side copies
+    size_t wpk_floats = 0;
+    // workspace arena
+    float *arena = nullptr;
+    size_t arena_floats = 0;
+    int wsB = 0, wsH = 0, wsW = 0;
+    // options
+    int use_graph = 0, profile = 0;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    // profiling
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<long long> prof_n;
+    std::vector<ProfEvent> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int prof_id(b2f_ctx *c, const char *name)
+{
+    for (size_t i = 0; i < c->prof_names.size(); ++i)
+        if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name);
+    c->prof_ms.push_back(0.0);
+    c->prof_n.push_back(0);
+    return (int)c->prof_names.size() - 1;
+}
+
+hipEvent_t get_event(b2f_ctx *c)
+{
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RAII bracket of one kernel launch with HIP events on the launch stream.
+struct Scope {
+    b2f_ctx *c;
+    hipStream_t s;
+    ProfEvent pe;
+    bool on;
+    Scope(b2f_ctx *c_, hipStream_t s_, const char *name, bool capturing) : c(c_), s(s_), on(c_->profile && !capturing)
+    {
+        if (on) {
+            pe.name = prof_id(c, name);
+            pe.a = get_event(c);
+            pe.b = get_event(c);
+            (void)hipEventRecord(pe.a, s);
+        }
+    }
+    ~Scope()
+    {
+        if (on) {
+            (void)hipEventRecord(pe.b, s);
+            c->prof_pending.push_back(pe);
+        }
+    }
+};
+
+int prof_collect(b2f_ctx *c)
+{
+    for (ProfEvent &pe : c->prof_pending) {
+        HIPCHK(hipEventSynchronize(pe.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
+        c->prof_ms[pe.name] += ms;
+        c->prof_n[pe.name] += 1;
+        c->ev_pool.push_back(pe.a);
+        c->ev_pool.push_back(pe.b);
+    }
+    c->prof_pending.clear();
+    return 0;
+}
+
+// ---- weight packing ------------------------------------------------------------------
+// Builds, for every conv of the canonical layout, the K-order the kernels consume:
+//   features / inner decoder layers : input channels in order, zero padded to 8
+//   decoder layer 1                 : segment 0 = cs[ref][l] (C_l channels),
+//                                     segment 1 = cost-volume record [fwd 81|bwd 81|u|v|..]
+// while the Torch order of pwc.lua:308,334 is {cv 162, cs[ref][l] C_l, flow 2}.
+int pack_all(b2f_ctx *c, const float *flat)
+{
+    const size_t n = c->lay.size();
+    c->packed.assign(n, PackedConv());
+    size_t total = 0;
+    std::vector<std::vector<int>> maps(n);
+    for (size_t i = 0; i < n; ++i) {
+        const ConvDesc &d = c->lay[i];
+        PackedConv &p = c->packed[i];
+        p.cout = d.co;
+        conv_choose_tiles(d.co, &p.nt, &p.nblk);
+        std::vector<int> &m = maps[i];
+        if (d.kind != KIND_FEAT && d.idx == 1) {
+            const int Cl = kFeat[d.level];
+            const bool has_feat = d.ci >= kND + Cl;          // level-7 flow decoder takes the cost volume only
+            const bool has_flow = d.ci == kND + Cl + 2;
+            if (has_feat) {
+                p.nseg = 2;
+                p.chunks[0] = Cl / kCK;
+                for (int k = 0; k < Cl; ++k) m.push_back(kND + k);
+            } else {
+                p.nseg = 1;
+            }
+            const int rec_chunks = (kCvRec + kCK - 1) / kCK;   // 21
+            p.chunks[p.nseg - 1] = rec_chunks;
+            for (int k = 0; k < rec_chunks * kCK; ++k) {
+                int ci = -1;
+                if (k < kND) ci = k;
+                else if (k < kND + 2 && has_flow) ci = kND + Cl + (k - kND);
+                m.push_back(ci);
+            }
+        } else {
+            p.nseg = 1;
+            p.chunks[0] = (d.ci + kCK - 1) / kCK;
+            for (int k = 0; k < p.chunks[0] * kCK; ++k) m.push_back(k < d.ci ? k : -1);
+        }
+        const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
+        p.w_off = total;
+        total += conv_wpk_floats(chunks, p.nt, p.nblk);
+        p.b_off = total;
+        total += (size_t)p.nblk * p.nt * 32;
+    }
+    std::vector<float> host(total, 0.f);
+    for (size_t i = 0; i < n; ++i) {
+        const ConvDesc &d = c->lay[i];
+        const PackedConv &p = c->packed[i];
+        const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
+        conv_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
+                          host.data() + p.w_off, host.data() + p.b_off);
+    }
+    if (c->wpk_floats != total) {
+        if (c->wpk_dev) HIPCHK(hipFree(c->wpk_dev));
+        c->wpk_dev = nullptr;
+        HIPCHK(hipMalloc(&c->wpk_dev, total * sizeof(float)));
+        c->wpk_floats = total;
+    }
+    HIPCHK(hipMemcpy(c->wpk_dev, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    // a packed layout change invalidates captured graphs only through pointers; they stay valid
+    return 0;
+}
+
+int find_conv(const b2f_ctx *c, int kind, int level, int idx)
+{
+    for (size_t i = 0; i < c->lay.size(); ++i)
+        if (c->lay[i].kind == kind && c->lay[i].level == level && c->lay[i].idx == idx) return (int)i;
+    return -1;
+}
+
+// ---- workspace -------------------------------------------------------------------------
+struct Plan {
+    int B, H, W;
+    int h[8], w[8];
+    size_t img, tmp, cs[8], U[8], cv, d[6], fs, logits, u2, flow_planar, total;
+};
+
+Plan make_plan(int B, int H, int W)
+{
+    Plan p;
+    p.B = B; p.H = H; p.W = W;
+    for (int l = 1; l <= 7; ++l) { p.h[l] = H >> (l - 1); p.w[l] = W >> (l - 1); }
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
+    p.img = take((size_t)3 * B * H * W * kImgC);
+    p.tmp = take((size_t)3 * B * p.h[2] * p.w[2] * kFeat[2]);
+    for (int l = 2; l <= 7; ++l) p.cs[l] = take((size_t)3 * B * p.h[l] * p.w[l] * kFeat[l]);
+    for (int l = 3; l <= 6; ++l) p.U[l] = take((size_t)B * p.h[l] * p.w[l] * 2);
+    p.cv = take((size_t)B * p.h[3] * p.w[3] * kCvRec + 64);
+    const size_t px3 = (size_t)B * p.h[3] * p.w[3];
+    for (int i = 1; i <= 5; ++i) p.d[i] = take(px3 * kDec[i]);
+    p.fs = take(px3 * 2);
+    p.logits = take(px3 * 2);
+    p.u2 = take(px3 * 4 * 2);
+    p.flow_planar = take((size_t)B * 2 * H * W);
+    p.total = off;
+    return p;
+}
+
+int ensure_workspace(b2f_ctx *c, const Plan &p)
+{
+    if (p.total > c->arena_floats) {
+        if (c->arena) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(c->arena));
+            c->arena = nullptr;
+            for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+            c->graphs.clear();
+        }
+        HIPCHK(hipMalloc(&c->arena, p.total * sizeof(float)));
+        HIPCHK(hipMemset(c->arena, 0, p.total * sizeof(float)));
+        c->arena_floats = p.total;
+    }
+    return 0;
+}
+
+// ---- one conv launch from the packed table -----------------------------------------------
+int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *segs, int nimg, int H, int W,
+             int stride, int leaky, float *out, long out_img_stride, int out_pix_stride)
+{
+    const PackedConv &p = c->packed[conv_id];
+    ConvLaunch L;
+    L.nseg = p.nseg;
+    for (int i = 0; i < p.nseg; ++i) {
+        L.seg[i] = segs[i];
+        L.seg[i].nchunks = p.chunks[i];
+    }
+    if (p.nseg == 1) L.seg[1] = L.seg[0], L.seg[1].nchunks = 0;
+    L.wpk = c->wpk_dev + p.w_off;
+    L.bias = c->wpk_dev + p.b_off;
+    L.out = out;
+    L.out_img_stride = out_img_stride;
+    L.out_pix_stride = out_pix_stride;
+    L.cout = p.cout;
+    L.nt = p.nt;
+    L.nblk = p.nblk;
+    L.H = H; L.W = W; L.stride = stride;
+    L.Ho = (H + 2 - 3) / stride + 1;
+    L.Wo = (W + 2 - 3) / stride + 1;
+    L.nimg = nimg;
+    L.leaky = leaky;
+    char name[32];
+    snprintf(name, sizeof name, "conv3x3_s%d_nt%d", stride, p.nt);
+    Scope sc(c, s, name, cap);
+    HIPCHK(launch_conv3x3(L, s));
+    return 0;
+}
+
+// decoder(n) of pwc.lua:76-85 at level l; input = {cs[ref][l], cost-volume record}
+int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, int l, float *out2)
+{
+    float *A = c->arena;
+    const int h = P.h[l], w = P.w[l], B = P.B;
+    const size_t hw = (size_t)h * w;
+    const int Cl = kFeat[l];
+    const int id1 = find_conv(c, kind, l, 1);
+    if (id1 < 0) return fail("decoder not present in this model");
+    ConvSeg segs[2];
+    const ConvSeg seg_ref = {A + P.cs[l] + (size_t)1 * B * hw * Cl, (long)(hw * Cl), Cl, 0};
+    const ConvSeg seg_cv = {A + P.cv, (long)(hw * kCvRec), kCvRec, 0};
+    if (c->packed[id1].nseg == 2) { segs[0] = seg_ref; segs[1] = seg_cv; }
+    else { segs[0] = seg_cv; segs[1] = seg_cv; }
+    CHK(run_conv(c, s, cap, id1, segs, B, h, w, 1, 1, A + P.d[1], (long)(hw * kDec[1]), kDec[1]));
+    for (int i = 2; i <= 6; ++i) {
+        const ConvSeg in = {A + P.d[i - 1], (long)(hw * kDec[i - 1]), kDec[i - 1], 0};
+        float *o = (i == 6) ? out2 : A + P.d[i];
+        const int oc = (i == 6) ? 2 : kDec[i];
+        CHK(run_conv(c, s, cap, find_conv(c, kind, l, i), &in, B, h, w, 1, i < 6, o, (long)(hw * oc), oc));
+    }
+    return 0;
+}
+
+// The pruned computeFlow graph (SURVEY.md Appendix B "live set").
+int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, const Plan &P,
+                 float *dev_flow, float *dev_occ, float *dev_est3)
+{
+    float *A = c->arena;
+    const int B = P.B;
+    {
+        Scope sc(c, s, "pack_input", cap);
+        HIPCHK(launch_pack_input((const float *)dev_in, in_kind == B2F_IN_UNIT, B, P.H, P.W, A + P.img, s));
+    }
+    // siamese feature pyramid, the three frames batched (shared weights, pwc.lua:169-211)
+    for (int l = 2; l <= 7; ++l) {
+        const int hi = P.h[l - 1], wi = P.w[l - 1], ho = P.h[l], wo = P.w[l];
+        const int Ci = (l == 2) ? kImgC : kFeat[l - 1], Co = kFeat[l];
+        const ConvSeg in1 = {(l == 2) ? A + P.img : A + P.cs[l - 1], (long)((size_t)hi * wi * Ci), Ci, 0};
+        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp,
+                     (long)((size_t)ho * wo * Co), Co));
+        const ConvSeg in2 = {A + P.tmp, (long)((size_t)ho * wo * Co), Co, 0};
+        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l],
+                     (long)((size_t)ho * wo * Co), Co));
+    }
+    for (int l = 7; l >= 3; --l) {   // pwc.lua:237
+        const int h = P.h[l], w = P.w[l], Cl = kFeat[l];
+        const size_t hw = (size_t)h * w;
+        CorrLaunch cl;
+        cl.ref = A + P.cs[l] + (size_t)1 * B * hw * Cl;
+        cl.nbr_fut = A + P.cs[l] + (size_t)2 * B * hw * Cl;
+        cl.nbr_past = A + P.cs[l];
+        cl.img_stride = (long)(hw * Cl);
+        cl.pix_stride = Cl;
+        cl.flow = (l < 7) ? A + P.U[l] : nullptr;
+        cl.k = (float)(20.0 / std::pow(2.0, l - 1));   // nn.MulConstant(20*(f-ref)/2^(l-2)) one level up, pwc.lua:404
+        cl.out = A + P.cv;
+        cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
+        {
+            Scope sc(c, s, "warp_costvol", cap);
+            HIPCHK(launch_warp_costvol(cl, s));
+        }
+        CHK(run_decoder(c, s, cap, P, KIND_FLOW, l, A + P.fs));
+        if (l > 3) {
+            Scope sc(c, s, "upsample_flow2x", cap);
+            HIPCHK(launch_upsample_flow2x(A + P.fs, B, h, w, A + P.U[l - 1], s));   // ufs[l], pwc.lua:360
+        }
+    }
+    // finest level: skip_ufs[3] = two bilinear x2 (pwc.lua:359-390), occs[3] -> skip_occs[3]
+    float *flow_out = dev_flow ? dev_flow : A + P.flow_planar;
+    {
+        Scope sc(c, s, "upsample_flow2x", cap);
+        HIPCHK(launch_upsample_flow2x(A + P.fs, B, P.h[3], P.w[3], A + P.u2, s));
+        HIPCHK(launch_upsample_flow2x_planar(A + P.u2, B, P.h[2], P.w[2], flow_out, s));
+    }
+    const bool want_occ = dev_occ || (dev_est3 && c->past_flow);
+    if (want_occ) {
+        CHK(run_decoder(c, s, cap, P, KIND_OCC, 3, A + P.logits));
+        Scope sc(c, s, "softmax_nearest4", cap);
+        if (dev_occ) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, P.h[3], P.w[3], dev_occ, s));
+        if (dev_est3 && c->past_flow)   // Soft: est[3] = skip_occs[3]
+            HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, P.h[3], P.w[3], dev_est3, s));
+    }
+    if (dev_est3 && !c->past_flow) {
+        // Hard: est[3] = iws[1][3] = warp(I1, skip_ufs[3] * 20*(1-2)/2^0)  (pwc.lua:422-446,459-489)
+        Scope sc(c, s, "warp_image", cap);
+        HIPCHK(launch_warp_image_planar(A + P.img, flow_out, -20.0f, B, P.H, P.W, dev_est3, s));
+    }
+    return 0;
+}
+
+int check_shape(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return fail("b2f: non-positive shape");
+    if (H % 64 || W % 64) return fail("b2f: H and W must be multiples of 64 (7 pyramid levels, back2future.lua:54-67)");
+    return 0;
+}
+
+bool parse_random(const char *name, bool *past, unsigned long long *seed, float *gain)
+{
+    if (strncmp(name, "random:", 7) != 0) return false;
+    std::string s(name + 7);
+    std::vector<std::string> parts;
+    size_t pos = 0;
+    while (true) {
+        size_t q = s.find(':', pos);
+        parts.push_back(s.substr(pos, q == std::string::npos ? q : q - pos));
+        if (q == std::string::npos) break;
+        pos = q + 1;
+    }
+    if (parts[0] == "hard") *past = false;
+    else if (parts[0] == "soft") *past = true;
+    else return false;
+    *seed = 2;   // manualSeed default, opts.lua:27
+    *gain = 1.f;
+    if (parts.size() > 1 && !parts[1].empty()) *seed = strtoull(parts[1].c_str(), nullptr, 10);
+    if (parts.size() > 2 && !parts[2].empty()) *gain = strtof(parts[2].c_str(), nullptr);
+    return true;
+}
+
+bool ends_with(const std::string &s, const char *suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int install_weights(b2f_ctx *c, const float *flat, long long n, bool past)
+{
+    if (n != param_count(past)) return fail("b2f: weight count does not match the architecture");
+    if (c->w_dev && (c->nparams != n)) { HIPCHK(hipFree(c->w_dev)); c->w_dev = nullptr; }
+    c->past_flow = past;
+    c->nparams = n;
+    long long t = 0;
+    c->lay = weight_layout(past, &t);
+    if (!c->w_dev) HIPCHK(hipMalloc(&c->w_dev, (size_t)n * sizeof(float)));
+    HIPCHK(hipMemcpy(c->w_dev, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return pack_all(c, flat);
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+const char *b2f_last_error(void) { return g_err.c_str(); }
+int b2f_version(void) { return 1000; }
+
+long long b2f_param_count(int past_flow) { return param_count(past_flow != 0); }
+
+int b2f_random_weights(unsigned long long seed, int past_flow, float gain, float *out, long long n)
+{
+    if (!out || n != param_count(past_flow != 0)) return fail("b2f_random_weights: bad buffer size");
+    random_weights(seed, past_flow != 0, gain, out);
+    return 0;
+}
+
+int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *past_flow)
+{
+    std::vector<float> flat;
+    bool past = false;
+    std::string err;
+    if (!path) return fail("b2f_load_t7: null path");
+    if (!load_t7(path, flat, past, err)) return fail("b2f_load_t7: " + err);
+    if (n) *n = (long long)flat.size();
+    if (past_flow) *past_flow = past ? 1 : 0;
+    if (out) {
+        if (cap < (long long)flat.size()) return fail("b2f_load_t7: output buffer too small");
+        memcpy(out, flat.data(), flat.size() * sizeof(float));
+    }
+    return 0;
+}
+
+int b2f_init(const char *name_or_path, int device, b2f_ctx **out)
+{
+    if (!out) return fail("b2f_init: null out");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("b2f_init: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("b2f_init: bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    const char *name = name_or_path ? name_or_path : "Ours-Soft-ft-KITTI";   // back2future.lua:98
+    std::vector<float> flat;
+    bool past = false;
+    unsigned long long seed = 2;
+    float gain = 1.f;
+    if (parse_random(name, &past, &seed, &gain)) {
+        flat.resize((size_t)param_count(past));
+        random_weights(seed, past, gain, flat.data());
+    } else {
+        std::string path = name;
+        if (path == "Ours-Hard") path = "models/RoamingImages_H.t7";                      // :100-102
+        else if (path == "Ours-Soft-ft-KITTI") path = "models/RoamingImages_H_KITTI_S.t7";   // :104-106
+        else if (path == "Ours-Soft-ft-Sintel") path = "models/RoamingImages_H_Sintel_S.t7"; // :108-110
+        if (ends_with(path, ".t7")) {
+            std::string err;
+            if (!load_t7(path, flat, past, err)) return fail("b2f_init: " + err);
+        } else if (ends_with(path, ".b2fw")) {
+            FILE *f = fopen(path.c_str(), "rb");
+            if (!f) return fail("b2f_init: cannot open " + path);
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            flat.resize((size_t)sz / 4);
+            const size_t rd = fread(flat.data(), 4, flat.size(), f);
+            fclose(f);
+            if (rd != flat.size()) return fail("b2f_init: short read on " + path);
+            if ((long long)flat.size() == param_count(true)) past = true;
+            else if ((long long)flat.size() == param_count(false)) past = false;
+            else return fail("b2f_init: " + path + " does not hold a Hard or Soft parameter set");
+        } else {
+            return fail(std::string("b2f_init: unknown model '") + name + "'");
+        }
+    }
+    b2f_ctx *c = new b2f_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail("b2f_init: hipStreamCreate failed");
+    }
+    if (install_weights(c, flat.data(), (long long)flat.size(), past) != 0) {
+        b2f_destroy(c);
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+void b2f_destroy(b2f_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    for (ProfEvent &pe : c->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->wpk_dev) (void)hipFree(c->wpk_dev);
+    if (c->w_dev) (void)hipFree(c->w_dev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int b2f_info(const b2f_ctx *c, int *levels, int *win, int *past_flow, int *n_outputs, long long *n_params)
+{
+    if (!c) return fail("b2f_info: null context");
+    if (levels) *levels = kLevels;
+    if (win) *win = kWin;
+    if (past_flow) *past_flow = c->past_flow ? 1 : 0;
+    if (n_outputs) *n_outputs = (kLevels - kLst + 1) * (c->past_flow ? 5 : 4);   // pwc.lua:459-489
+    if (n_params) *n_params = c->nparams;
+    return 0;
+}
+
+int b2f_set_weights(b2f_ctx *c, const float *host_flat, long long n)
+{
+    if (!c || !host_flat) return fail("b2f_set_weights: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bool past;
+    if (n == param_count(true)) past = true;
+    else if (n == param_count(false)) past = false;
+    else return fail("b2f_set_weights: n is neither the Hard nor the Soft parameter count");
+    return install_weights(c, host_flat, n, past);
+}
+
+int b2f_get_weights(b2f_ctx *c, float *host_flat, long long n)
+{
+    if (!c || !host_flat || n != c->nparams) return fail("b2f_get_weights: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(host_flat, c->w_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int b2f_weights_device(b2f_ctx *c, void **dev_ptr, long long *n)
+{
+    if (!c || !dev_ptr) return fail("b2f_weights_device: null argument");
+    *dev_ptr = c->w_dev;
+    if (n) *n = c->nparams;
+    return 0;
+}
+
+int b2f_commit_weights(b2f_ctx *c)
+{
+    if (!c) return fail("b2f_commit_weights: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> flat((size_t)c->nparams);
+    HIPCHK(hipMemcpy(flat.data(), c->w_dev, flat.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return pack_all(c, flat.data());
+}
+
+int b2f_set_option(b2f_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return fail("b2f_set_option: null argument");
+    if (!strcmp(key, "use_graph")) c->use_graph = value;
+    else if (!strcmp(key, "profile")) c->profile = value;
+    else return fail(std::string("b2f_set_option: unknown key ") + key);
+    return 0;
+}
+
+int b2f_synchronize(b2f_ctx *c)
+{
+    if (!c) return fail("b2f_synchronize: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int b2f_profile_reset(b2f_ctx *c)
+{
+    if (!c) return fail("b2f_profile_reset: null context");
+    CHK(prof_collect(c));
+    std::fill(c->prof_ms.begin(), c->prof_ms.end(), 0.0);
+    std::fill(c->prof_n.begin(), c->prof_n.end(), 0);
+    return 0;
+}
+
+int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launches, int cap, int *n)
+{
+    if (!c || !n) return fail("b2f_profile_read: null argument");
+    CHK(prof_collect(c));
+    const int cnt = std::min<int>(cap, (int)c->prof_names.size());
+    for (int i = 0; i < cnt; ++i) {
+        if (names) { strncpy(names + 32 * i, c->prof_names[i].c_str(), 31); names[32 * i + 31] = 0; }
+        if (total_ms) total_ms[i] = c->prof_ms[i];
+        if (launches) launches[i] = c->prof_n[i];
+    }
+    *n = cnt;
+    return 0;
+}
+
+int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow,
+                       float *dev_occ, float *dev_est3, void *stream)
+{
+    if (!c || !dev_in) return fail("b2f_forward_device: null argument");
+    CHK(check_shape(B, H, W));
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const Plan P = make_plan(B, H, W);
+    CHK(ensure_workspace(c, P));
+    if (c->use_graph && !c->profile) {
+        const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = forward_impl(c, s, true, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3);
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            HIPCHK(e);
+            hipGraphExec_t ge = nullptr;
+            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            it = c->graphs.emplace(key, ge).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, s));
+        return 0;
+    }
+    return forward_impl(c, s, false, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3);
+}
+
+int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
+                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+{
+    if (!c || !im1 || !im2 || !im3 || !flow || !fwd_occ || !bwd_occ) return fail("b2f_compute_flow: null argument");
+    if (n <= 0 || H0 <= 0 || W0 <= 0) return fail("b2f_compute_flow: bad shape");
+    const int fw = W0 - W0 % 64, fh = H0 - H0 % 64;   // back2future.lua:54-67
+    if (fw <= 0 || fh <= 0) return fail("b2f_compute_flow: image smaller than 64 pixels");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
+    const bool same = (fw == W0 && fh == H0);
+    // torch.cat + (ColorNormalize) + image.scale (:48-71).  When no rescale is needed the raw
+    // [0,1] planes go up as they are and are normalized on the device; otherwise normalize and
+    // box-filter on the host exactly in the reference's order (normalize, then scale).
+    std::vector<float> stage((size_t)n * 9 * hw);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    std::vector<float> tmp;
+    if (!same) tmp.resize(9 * hw0);
+    for (int b = 0; b < n; ++b) {
+        const float *src[3] = {im1 + (size_t)b * 3 * hw0, im2 + (size_t)b * 3 * hw0, im3 + (size_t)b * 3 * hw0};
+        float *dst = stage.data() + (size_t)b * 9 * hw;
+        if (same) {
+            for (int f = 0; f < 3; ++f) memcpy(dst + (size_t)f * 3 * hw, src[f], 3 * hw * sizeof(float));
+        } else {
+            for (int f = 0; f < 3; ++f)
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float *s = src[f] + (size_t)ch * hw0;
+                    float *t = tmp.data() + ((size_t)f * 3 + ch) * hw0;
+                    for (size_t i = 0; i < hw0; ++i) t[i] = (s[i] + (-mean[ch])) / stdv[ch];
+                }
+            image_scale_bilinear(tmp.data(), 9, H0, W0, dst, fh, fw);
+        }
+    }
+    const int C3 = c->past_flow ? 2 : 3;
+    float *d_in = nullptr, *d_flow = nullptr, *d_est3 = nullptr;
+    HIPCHK(hipMalloc(&d_in, stage.size() * sizeof(float)));
+    HIPCHK(hipMalloc(&d_flow, (size_t)n * 2 * hw * sizeof(float)));
+    HIPCHK(hipMalloc(&d_est3, (size_t)n * C3 * hw * sizeof(float)));
+    int rc = 0;
+    std::vector<float> h_flow((size_t)n * 2 * hw), h_est3((size_t)n * C3 * hw);
+    do {
+        if (hipMemcpyAsync(d_in, stage.data(), stage.size() * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail("H2D copy failed"); break; }
+        rc = b2f_forward_device(c, d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, n, fh, fw, d_flow, nullptr, d_est3, c->stream);
+        if (rc) break;
+        if (hipMemcpyAsync(h_flow.data(), d_flow, h_flow.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_est3.data(), d_est3, h_est3.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(std::string("D2H copy failed: ") + hipGetErrorString(hipGetLastError())); break; }
+    } while (0);
+    (void)hipFree(d_in); (void)hipFree(d_flow); (void)hipFree(d_est3);
+    if (rc) return rc;
+    for (int b = 0; b < n; ++b)
+        postprocess(h_flow.data() + (size_t)b * 2 * hw, h_est3.data() + (size_t)b * C3 * hw, C3, fh, fw, H0, W0,
+                    flow + (size_t)b * 2 * hw0, fwd_occ + (size_t)b * hw0, bwd_occ + (size_t)b * hw0);
+    return 0;
+}
+
+int b2f_compute_flow(b2f_ctx *c, const float *im1, const float *im2, const float *im3, int H0, int W0,
+                     double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+{
+    return b2f_compute_flow_batch(c, 1, im1, im2, im3, H0, W0, flow, fwd_occ, bwd_occ);
+}
+
+int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow, int cap)
+{
+    if (!c) return fail("b2f_output_shapes: null context");
+    int no = 0;
+    for (int l = kLst; l <= kLevels; ++l) {
+        const int per = c->past_flow ? 5 : 4;
+        for (int j = 0; j < per; ++j) {
+            if (no >= cap) return fail("b2f_output_shapes: cap too small");
+            ch[no] = (j >= per - 2) ? 3 : 2;
+            oh[no] = (H >> (l - 1)) * 4;
+            ow[no] = (W >> (l - 1)) * 4;
+            ++no;
+        }
+    }
+    return 0;
+}
+
+int b2f_forward(b2f_ctx *, const float *, int, int, int, float **, int)
+{
+    return fail("b2f_forward: the full model:forward output table is not implemented yet (SURVEY s8f row 3)");
+}
+
+// ---- op-level entry points (host pointers; reference module layouts) -----------------------
+namespace {
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float))); return 0; }
+};
+}  // namespace
+
+int b2f_op_warp_bhwd(b2f_ctx *c, const float *img, const float *grid, int B, int ih, int iw, int C, int gh,
+                     int gw, float *out)
+{
+    if (!c || !img || !grid || !out) return fail("b2f_op_warp_bhwd: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf di, dg, dout;
+    const size_t ni = (size_t)B * ih * iw * C, ng = (size_t)B * gh * gw * 2, no = (size_t)B * gh * gw * C;
+    CHK(di.alloc(ni)); CHK(dg.alloc(ng)); CHK(dout.alloc(no));
+    HIPCHK(hipMemcpy(di.p, img, ni * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dg.p, grid, ng * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_warp_nhwc(di.p, (long)((size_t)ih * iw * C), C, C, ih, iw, dg.p, 1.0f, B, gh, gw, dout.p, C, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout.p, no * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int b2f_op_upsample_flow2x(b2f_ctx *c, const float *x, int B, int h, int w, float *y)
+{
+    if (!c || !x || !y) return fail("b2f_op_upsample_flow2x: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf dp, dn, dy;
+    const size_t n = (size_t)B * 2 * h * w;
+    CHK(dp.alloc(n)); CHK(dn.alloc(n)); CHK(dy.alloc(4 * n));
+    HIPCHK(hipMemcpy(dp.p, x, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_planar_to_nhwc(dp.p, 2, B, h, w, dn.p, 2, c->stream));
+    HIPCHK(launch_upsample_flow2x_planar(dn.p, B, h, w, dy.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(y, dy.p, 4 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, const float *nbr_past,
+                        const float *flow, float k, int B, int C, int h, int w, float *out)
+{
+    if (!c || !ref || !nbr_future || !nbr_past || !out) return fail("b2f_op_warp_costvol: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int Cp = (C + 7) / 8 * 8;   // the fused kernel walks channels in chunks of 8; zero channels add 0
+    const size_t hw = (size_t)h * w, nplanar = (size_t)B * C * hw, nn = (size_t)B * hw * Cp;
+    DevBuf dpl, dr, df, dpa, dfl_pl, dfl, dcv, dout;
+    CHK(dpl.alloc(nplanar)); CHK(dr.alloc(nn)); CHK(df.alloc(nn)); CHK(dpa.alloc(nn));
+    CHK(dcv.alloc((size_t)B * hw * kCvRec)); CHK(dout.alloc((size_t)B * kND * hw));
+    const float *srcs[3] = {ref, nbr_future, nbr_past};
+    float *dsts[3] = {dr.p, df.p, dpa.p};
+    for (int i = 0; i < 3; ++i) {
+        HIPCHK(hipMemcpyAsync(dpl.p, srcs[i], nplanar * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_planar_to_nhwc(dpl.p, C, B, h, w, dsts[i], Cp, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (flow) {
+        CHK(dfl_pl.alloc((size_t)B * 2 * hw)); CHK(dfl.alloc((size_t)B * 2 * hw));
+        HIPCHK(hipMemcpy(dfl_pl.p, flow, (size_t)B * 2 * hw * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(launch_planar_to_nhwc(dfl_pl.p, 2, B, h, w, dfl.p, 2, c->stream));
+    }
+    CorrLaunch cl;
+    cl.ref = dr.p; cl.nbr_fut = df.p; cl.nbr_past = dpa.p;
+    cl.img_stride = (long)(hw * Cp); cl.pix_stride = Cp;
+    cl.flow = flow ? dfl.p : nullptr;
+    cl.k = k; cl.out = dcv.p; cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
+    HIPCHK(launch_warp_costvol(cl, c->stream));
+    HIPCHK(launch_nhwc_to_planar(dcv.p, kCvRec, kND, B, h, w, dout.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)B * kND * hw * sizeof(float), hipMemcpyDeviceToHost));
+    if (Cp != C) {   // the kernel divided by Cp; CostVolMulti.lua:100 divides by N = C
+        const size_t n = (size_t)B * kND * hw;
+        for (size_t i = 0; i < n; ++i) out[i] = out[i] * (float)Cp / (float)C;
+    }
+    return 0;
+}
+
+int b2f_op_costvol(b2f_ctx *c, const float *ref, const float *frm, int B, int C, int h, int w, int win, int fwd,
+                   float *out)
+{
+    if (!c || !ref || !frm || !out) return fail("b2f_op_costvol: null argument");
+    if (win < 1 || win % 2 == 0) return fail("b2f_op_costvol: win must be odd");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t hw = (size_t)h * w;
+    if (win == kWin && C % 8 == 0) {
+        // the shipped 9x9 window goes through the fused kernel (no warp): one half of its record
+        std::vector<float> both((size_t)B * kND * hw);
+        CHK(b2f_op_warp_costvol(c, ref, frm, frm, nullptr, 0.f, B, C, h, w, both.data()));
+        for (int b = 0; b < B; ++b)
+            memcpy(out + (size_t)b * 81 * hw, both.data() + ((size_t)b * kND + (fwd ? 0 : 81)) * hw, 81 * hw * sizeof(float));
+        return 0;
+    }
+    DevBuf dpl, dr, df, dcv, dout;
+    const size_t nin = (size_t)B * C * hw, nout = (size_t)B * win * win * hw;
+    CHK(dpl.alloc(nin)); CHK(dr.alloc(nin)); CHK(df.alloc(nin)); CHK(dcv.alloc(nout)); CHK(dout.alloc(nout));
+    HIPCHK(hipMemcpy(dpl.p, ref, nin * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_planar_to_nhwc(dpl.p, C, B, h, w, dr.p, C, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dpl.p, frm, nin * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_planar_to_nhwc(dpl.p, C, B, h, w, df.p, C, c->stream));
+    HIPCHK(launch_costvol_generic(dr.p, df.p, B, C, h, w, win, fwd, dcv.p, c->stream));
+    HIPCHK(launch_nhwc_to_planar(dcv.p, win * win, win * win, B, h, w, dout.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, dout.p, nout * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, const float *wt, const float *bias,
+                   int Co, int stride, int leaky, float *y)
+{
+    if (!c || !x || !wt || !bias || !y) return fail("b2f_op_conv3x3: null argument");
+    if (stride != 1 && stride != 2) return fail("b2f_op_conv3x3: stride must be 1 or 2");
+    HIPCHK(hipSetDevice(c->device));
+    const int chunks = (Ci + kCK - 1) / kCK, Cp = chunks * kCK;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    int nt, nblk;
+    conv_choose_tiles(Co, &nt, &nblk);
+    std::vector<float> wpk(conv_wpk_floats(chunks, nt, nblk)), bpk((size_t)nblk * nt * 32);
+    conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
+    DevBuf dpl, dx, dw, db, dy, dyp;
+    const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
+    CHK(dpl.alloc(nx)); CHK(dx.alloc(nxp)); CHK(dw.alloc(wpk.size())); CHK(db.alloc(bpk.size())); CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
+    HIPCHK(hipMemcpy(dpl.p, x, nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw.p, wpk.data(), wpk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db.p, bpk.data(), bpk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_planar_to_nhwc(dpl.p, Ci, B, H, W, dx.p, Cp, c->stream));
+    ConvLaunch L;
+    L.nseg = 1;
+    L.seg[0] = {dx.p, (long)((size_t)H * W * Cp), Cp, chunks};
+    L.seg[1] = L.seg[0];
+    L.seg[1].nchunks = 0;
+    L.wpk = dw.p; L.bias = db.p; L.out = dy.p;
+    L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_pix_stride = Co; L.cout = Co;
+    L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
+    HIPCHK(launch_conv3x3(L, c->stream));
+    HIPCHK(launch_nhwc_to_planar(dy.p, Co, Co, B, Ho, Wo, dyp.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(y, dyp.p, ny * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

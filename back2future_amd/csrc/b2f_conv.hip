@@ -1,0 +1,246 @@
+// conv3x3 as an fp32 MFMA implicit GEMM for gfx950 (MI355X).
+//
+// Replaces nn.SpatialConvolution(Ci,Co,3,3,s,s,1,1) [+ nn.LeakyReLU(0.2,true)] of
+// /root/reference/models/pwc.lua:58-65 (convUnit) and :76-85 (decoder), which the
+// reference runs through cuDNN (model.lua:63-65).  This is the MFMA-bound ~90 % of the
+// FLOPs of computeFlow.
+//
+// GEMM view: M = output pixels, N = output channels, K = 9 taps x Cin.
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles / 4096 FLOP.
+//   * block = 256 threads = 4 waves; block tile = 128 pixels (TH x TW) x NT*32 channels;
+//     wave w owns one 32-pixel M tile and all NT N tiles (NT <= 4 -> <= 64 acc VGPRs).
+//   * K is walked in chunks of 8 input channels.  Per chunk the block stages in LDS
+//       A: the input patch with halo, im2col done by address arithmetic at read time,
+//          laid out [k4 = 2][patch pixel] of float4 so that a half-wave reads 32
+//          neighbouring pixels x 4 channels with one conflict-free ds_read_b128;
+//       B: the pre-packed weight slab [tap 9][k4 2][NT*32 cout] of float4 (a straight
+//          linear copy of the packed global layout).
+//     Lane l = (n|m = l & 31, half = l >> 5).  For the 32x32x2 MFMA a lane supplies
+//     A[m][k = half] and B[k = half][n]; half h holds channels 4h..4h+3 of the chunk, so
+//     one b128 per operand feeds four consecutive MFMAs (k-pair j = {j, 4 + j}).
+//   * next chunk's global loads are issued before the MFMAs of the current one and
+//     written to LDS after it (register prefetch), two barriers per chunk.
+//   * input may come from up to two K segments (pointer, pixel stride, #chunks): the
+//     decoder's first layer reads {cs[ref][l], cost-volume record} without a JoinTable
+//     copy (pwc.lua:308,334).
+//   * epilogue: accumulators start at the bias, LeakyReLU fused, NHWC store (a half-wave
+//     writes 32 consecutive channels of one pixel = 128 B).
+#include "b2f_internal.h"
+
+namespace b2f {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int S, int TW>
+struct ConvGeom {
+    static constexpr int TH = 128 / TW;
+    static constexpr int PH = (TH - 1) * S + 3;
+    static constexpr int PW = (TW - 1) * S + 3;
+    static constexpr int NPIX = PH * PW;
+    static constexpr int A_F4 = 2 * NPIX;                 // float4 slots of the A patch
+    static constexpr int A_PER_THREAD = (A_F4 + 255) / 256;
+};
+
+template <int S, int NT, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
+{
+    using G = ConvGeom<S, TW>;
+    constexpr int NPIX = G::NPIX, PW = G::PW;
+    constexpr int NTOT = NT * 32;
+    constexpr int B_F4 = 9 * 2 * NTOT;
+    constexpr int B_PER_THREAD = (B_F4 + 255) / 256;
+    constexpr int A_PER_THREAD = G::A_PER_THREAD;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *ldsA = reinterpret_cast<float4 *>(smem);
+    float4 *ldsB = ldsA + G::A_F4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, half = lane >> 5;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::TH - 1) / G::TH;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int nb = blockIdx.y;
+    const int ox0 = tx_i * TW, oy0 = ty_i * G::TH;
+    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
+
+    // ---- per-thread staging coordinates for the A patch (fixed over chunks) ----
+    int a_goff[A_PER_THREAD];   // float offset inside the image (pixel part), -1 = zero fill
+    int a_lds[A_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+        const int idx = tid + i * 256;
+        const int pix = idx >> 1, h = idx & 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool ok = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_goff[i] = ok ? (gy * p.W + gx) : -1;
+        a_lds[i] = (idx < G::A_F4) ? (h * NPIX + pix) : -1;
+    }
+    const int a_h4 = (tid & 1) * 4;
+
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const float4 *wsrc = reinterpret_cast<const float4 *>(p.wpk) + (size_t)nb * nchunks * B_F4;
+
+    float4 ra[A_PER_THREAD], rb[B_PER_THREAD];
+    auto issue_loads = [&](int c) {
+        const bool s1 = c >= p.seg[0].nchunks;
+        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;
+        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;
+        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;
+        const int cc = s1 ? c - p.seg[0].nchunks : c;
+        const float *ib = base + (size_t)img * istr + cc * kCK + a_h4;
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i) {
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_goff[i] >= 0) ra[i] = *reinterpret_cast<const float4 *>(ib + (size_t)a_goff[i] * pstr);
+        }
+        const float4 *wb = wsrc + (size_t)c * B_F4;
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < B_F4) rb[i] = wb[idx];
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i)
+            if (a_lds[i] >= 0) ldsA[a_lds[i]] = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < B_F4) ldsB[idx] = rb[i];
+        }
+    };
+
+    // ---- accumulators start at the bias (same order as y = b + sum in nn) ----
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float bv = p.bias[nb * NTOT + t * 32 + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = bv;
+    }
+
+    // this lane's A pixel (M index m = lane & 31) inside the patch
+    const int m_ty = (TW == 32) ? wave : (2 * wave + (n >> 4));
+    const int m_tx = (TW == 32) ? n : (n & 15);
+    const float4 *aptr = ldsA + half * NPIX + (m_ty * S) * PW + m_tx * S;
+    const float4 *bptr = ldsB + half * NTOT + n;
+
+    issue_loads(0);
+    for (int c = 0; c < nchunks; ++c) {
+        write_lds();
+        __syncthreads();
+        if (c + 1 < nchunks) issue_loads(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const float4 a = aptr[ky * PW + kx];
+            float4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = bptr[tap * 2 * NTOT + t * 32];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31 (cout), row = (r&3) + 8*(r>>2) + 4*half ----
+    float *ob = p.out + (size_t)img * p.out_img_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = nb * NTOT + t * 32 + n;
+        if (co >= p.cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int ty = (TW == 32) ? wave : (2 * wave + (m >> 4));
+            const int tx = (TW == 32) ? m : (m & 15);
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            if (oy < p.Ho && ox < p.Wo) {
+                float v = acc[t][r];
+                if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+                ob[(size_t)(oy * p.Wo + ox) * p.out_pix_stride + co] = v;
+            }
+        }
+    }
+}
+
+template <int S, int NT, int TW>
+static hipError_t launch_t(const ConvLaunch &p, hipStream_t s)
+{
+    using G = ConvGeom<S, TW>;
+    const size_t lds = sizeof(float4) * (G::A_F4 + 9 * 2 * NT * 32);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::TH - 1) / G::TH;
+    dim3 grid((unsigned)(tiles_x * tiles_y * p.nimg), (unsigned)p.nblk);
+    hipLaunchKernelGGL((conv3x3_mfma<S, NT, TW>), grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int S, int TW>
+static hipError_t launch_nt(const ConvLaunch &p, hipStream_t s)
+{
+    switch (p.nt) {
+        case 1: return launch_t<S, 1, TW>(p, s);
+        case 2: return launch_t<S, 2, TW>(p, s);
+        case 3: return launch_t<S, 3, TW>(p, s);
+        case 4: return launch_t<S, 4, TW>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s)
+{
+    // 16-wide tiles for narrow maps (coarse pyramid levels), 32-wide otherwise
+    const bool narrow = (p.Wo <= 16) || (p.Wo % 32 != 0 && p.Wo % 32 <= 16 && p.Wo < 64);
+    if (p.stride == 1) return narrow ? launch_nt<1, 16>(p, s) : launch_nt<1, 32>(p, s);
+    if (p.stride == 2) return narrow ? launch_nt<2, 16>(p, s) : launch_nt<2, 32>(p, s);
+    return hipErrorInvalidValue;
+}
+
+void conv_choose_tiles(int cout, int *nt, int *nblk)
+{
+    const int n32 = (cout + 31) / 32;
+    if (n32 <= 4) { *nt = n32; *nblk = 1; }
+    else if (n32 % 3 == 0) { *nt = 3; *nblk = n32 / 3; }
+    else { *nt = 4; *nblk = (n32 + 3) / 4; }
+}
+
+size_t conv_wpk_floats(int cin_chunks, int nt, int nblk)
+{
+    return (size_t)nblk * cin_chunks * 9 * 2 * nt * 32 * 4;
+}
+
+void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
+                       int cin_chunks, int nt, int nblk, float *wpk, float *bpk)
+{
+    const int ntot = nt * 32;
+    for (int nb = 0; nb < nblk; ++nb)
+        for (int c = 0; c < cin_chunks; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int h = 0; h < 2; ++h)
+                    for (int nn = 0; nn < ntot; ++nn)
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = nb * ntot + nn;
+                            const int k = c * kCK + h * 4 + j;
+                            const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
+                            float v = 0.f;
+                            if (co < Co && ci >= 0) v = w[((size_t)co * Ci + ci) * 9 + tap];
+                            wpk[(((((size_t)nb * cin_chunks + c) * 9 + tap) * 2 + h) * ntot + nn) * 4 + j] = v;
+                        }
+    for (int i = 0; i < nblk * ntot; ++i) bpk[i] = i < Co ? b[i] : 0.f;
+}
+
+}  // namespace b2f

@@ -1,0 +1,292 @@
+// Small HBM-bound kernels around the two hot kernels: input packing, the stand-alone
+// bilinear sampler, flow upsampling, softmax + nearest upsampling, layout changes.
+// All NHWC fp32 on the device; planar (BDHW) only at the API boundary.
+#include "b2f_internal.h"
+
+namespace b2f {
+
+// ---- input: torch.cat + ColorNormalize + resize(1,9,H,W) (back2future.lua:48-49,73,
+// transforms.lua:33-45) and nn.Narrow(2,a,3) (pwc.lua:139-145): planar B x 9 x H x W ->
+// three frame-major NHWC images with 8 channels (RGB + 5 zeros = one conv K-chunk). ----
+__global__ void pack_input_kernel(const float *in, int normalize, int B, int H, int W, float *img)
+{
+    const size_t hw = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * hw) return;
+    const size_t b = i / hw, p = i - b * hw;
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float x = in[(b * 9 + f * 3 + c) * hw + p];
+            if (normalize) x = __fdiv_rn(x + (-mean[c]), stdv[c]);   // add(-mean) then div(std)
+            v[c] = x;
+        }
+        float4 *o = reinterpret_cast<float4 *>(img + (((size_t)f * B + b) * hw + p) * kImgC);
+        o[0] = make_float4(v[0], v[1], v[2], 0.f);
+        o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+hipError_t launch_pack_input(const float *in, int normalize, int B, int H, int W, float *img, hipStream_t s)
+{
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, normalize, B, H, W, img);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ void top_left_g(float coord, int size, int &pt, float &wt)
+{
+    float c = coord;   // getTopLeft, BilinearSamplerBHWD.cu:6-20
+    if (c < 0.f) c = 0.f;
+    if (c > (float)(size - 1)) c = (float)(size - 1);
+    const float fl = floorf(c);
+    pt = (int)fl;
+    wt = 1.f - (c - fl);
+}
+
+// ---- nn.BilinearSamplerBHWD forward, CUDA semantics (BilinearSamplerBHWD.cu:41-115);
+// one thread per (output pixel, channel): consecutive lanes = consecutive channels. ----
+__global__ void warp_nhwc_kernel(const float *img, long img_stride, int pix_stride, int C, int ih, int iw,
+                                 const float *grid, float k, int B, int gh, int gw, float *out,
+                                 int out_pix_stride)
+{
+    const size_t total = (size_t)B * gh * gw * C;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t pix = i / C;
+    const int x = (int)(pix % gw);
+    const size_t row = pix / gw;
+    const int y = (int)(row % gh);
+    const int b = (int)(row / gh);
+    const float2 g = *reinterpret_cast<const float2 *>(grid + pix * 2);
+    int xl, yt;
+    float wx, wy;
+    top_left_g(g.x * k + (float)x, iw, xl, wx);
+    top_left_g(g.y * k + (float)y, ih, yt, wy);
+    const float *src = img + (size_t)b * img_stride + ((size_t)yt * iw + xl) * pix_stride + c;
+    const bool x1 = xl + 1 <= iw - 1, y1 = yt + 1 <= ih - 1;
+    const float tl = src[0];
+    const float tr = x1 ? src[pix_stride] : 0.f;
+    const float bl = y1 ? src[(size_t)iw * pix_stride] : 0.f;
+    const float br = (x1 && y1) ? src[(size_t)(iw + 1) * pix_stride] : 0.f;
+    out[pix * out_pix_stride + c] = wx * wy * tl + (1.f - wx) * wy * tr + wx * (1.f - wy) * bl + (1.f - wx) * (1.f - wy) * br;
+}
+
+hipError_t launch_warp_nhwc(const float *img, long img_stride, int pix_stride, int C, int ih, int iw,
+                            const float *grid, float k, int B, int gh, int gw, float *out,
+                            int out_pix_stride, hipStream_t s)
+{
+    const size_t n = (size_t)B * gh * gw * C;
+    hipLaunchKernelGGL(warp_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, img_stride,
+                       pix_stride, C, ih, iw, grid, k, B, gh, gw, out, out_pix_stride);
+    return hipGetLastError();
+}
+
+// ---- nn.SpatialUpSamplingBilinear(2.0) on a 2-channel flow field (pwc.lua:360-381):
+// align-corners ratios, h1 = (int)(r*h2), lambda = r*h2 - h1, h1p = h1 < h-1. ----
+__device__ __forceinline__ float2 bilerp2(const float2 *in, int h, int w, float rh, float rw, int y2, int x2)
+{
+    const float h1r = rh * (float)y2;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < h - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float w1r = rw * (float)x2;
+    const int w1 = (int)w1r;
+    const int w1p = (w1 < w - 1) ? 1 : 0;
+    const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    const float2 *p = in + (size_t)h1 * w + w1;
+    const float2 a = p[0], b = p[w1p], c = p[(size_t)h1p * w], d = p[(size_t)h1p * w + w1p];
+    float2 o;
+    o.x = h0l * (w0l * a.x + w1l * b.x) + h1l * (w0l * c.x + w1l * d.x);
+    o.y = h0l * (w0l * a.y + w1l * b.y) + h1l * (w0l * c.y + w1l * d.y);
+    return o;
+}
+
+__global__ void upsample_flow2x_kernel(const float *in, int B, int h, int w, float *out, int planar)
+{
+    const int H2 = 2 * h, W2 = 2 * w;
+    const size_t n = (size_t)B * H2 * W2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x2 = (int)(i % W2);
+    const size_t r = i / W2;
+    const int y2 = (int)(r % H2);
+    const int b = (int)(r / H2);
+    const float rh = (H2 > 1) ? (float)(h - 1) / (float)(H2 - 1) : 0.f;
+    const float rw = (W2 > 1) ? (float)(w - 1) / (float)(W2 - 1) : 0.f;
+    const float2 o = bilerp2(reinterpret_cast<const float2 *>(in) + (size_t)b * h * w, h, w, rh, rw, y2, x2);
+    if (planar) {
+        const size_t hw2 = (size_t)H2 * W2;
+        out[((size_t)b * 2) * hw2 + (size_t)y2 * W2 + x2] = o.x;
+        out[((size_t)b * 2 + 1) * hw2 + (size_t)y2 * W2 + x2] = o.y;
+    } else {
+        reinterpret_cast<float2 *>(out)[i] = o;
+    }
+}
+
+hipError_t launch_upsample_flow2x(const float *in, int B, int h, int w, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * 4 * h * w;
+    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, h, w, out, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample_flow2x_planar(const float *in, int B, int h, int w, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * 4 * h * w;
+    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, h, w, out, 1);
+    return hipGetLastError();
+}
+
+// ---- nn.SpatialSoftMax over the 2 decoder logits (pwc.lua:308) + two
+// nn.SpatialUpSamplingNearest(2) (pwc.lua:311-321) -> planar B x 2 x 4h x 4w. ----
+__global__ void softmax_nearest4_kernel(const float *logits, int B, int h, int w, float *out)
+{
+    const int H4 = 4 * h, W4 = 4 * w;
+    const size_t n = (size_t)B * H4 * W4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int X = (int)(i % W4);
+    const size_t r = i / W4;
+    const int Y = (int)(r % H4);
+    const int b = (int)(r / H4);
+    const float2 z = reinterpret_cast<const float2 *>(logits)[((size_t)b * h + Y / 4) * w + X / 4];
+    const float m = fmaxf(z.x, z.y);
+    const float e0 = expf(z.x - m), e1 = expf(z.y - m);
+    const float sum = e0 + e1;
+    const size_t hw4 = (size_t)H4 * W4;
+    out[((size_t)b * 2) * hw4 + (size_t)Y * W4 + X] = e0 / sum;
+    out[((size_t)b * 2 + 1) * hw4 + (size_t)Y * W4 + X] = e1 / sum;
+}
+
+hipError_t launch_softmax_nearest4_planar(const float *logits, int B, int h, int w, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * 16 * h * w;
+    hipLaunchKernelGGL(softmax_nearest4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, B, h, w, out);
+    return hipGetLastError();
+}
+
+// ---- iws[1][3] for Hard models (pwc.lua:422-446): warp the full-resolution frame-1 image
+// by k * skip_ufs[3]; image is the packed NHWC8 copy, flow and output are planar. ----
+__global__ void warp_image_planar_kernel(const float *img8, const float *flow, float k, int B, int H, int W, float *out)
+{
+    const size_t hw = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * hw) return;
+    const size_t b = i / hw, p = i - b * hw;
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float u = flow[(b * 2) * hw + p] * k, v = flow[(b * 2 + 1) * hw + p] * k;
+    int xl, yt;
+    float wx, wy;
+    top_left_g(u + (float)x, W, xl, wx);
+    top_left_g(v + (float)y, H, yt, wy);
+    const float *src = img8 + (b * hw + (size_t)yt * W + xl) * kImgC;
+    const bool x1 = xl + 1 <= W - 1, y1 = yt + 1 <= H - 1;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 tl = *reinterpret_cast<const float4 *>(src);
+    const float4 tr = x1 ? *reinterpret_cast<const float4 *>(src + kImgC) : z;
+    const float4 bl = y1 ? *reinterpret_cast<const float4 *>(src + (size_t)W * kImgC) : z;
+    const float4 br = (x1 && y1) ? *reinterpret_cast<const float4 *>(src + (size_t)(W + 1) * kImgC) : z;
+    const float w00 = wx * wy, w01 = (1.f - wx) * wy, w10 = wx * (1.f - wy), w11 = (1.f - wx) * (1.f - wy);
+    out[(b * 3) * hw + p] = w00 * tl.x + w01 * tr.x + w10 * bl.x + w11 * br.x;
+    out[(b * 3 + 1) * hw + p] = w00 * tl.y + w01 * tr.y + w10 * bl.y + w11 * br.y;
+    out[(b * 3 + 2) * hw + p] = w00 * tl.z + w01 * tr.z + w10 * bl.z + w11 * br.z;
+}
+
+hipError_t launch_warp_image_planar(const float *img8, const float *flow_planar, float k, int B, int H, int W,
+                                    float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp_image_planar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img8, flow_planar, k, B, H, W, out);
+    return hipGetLastError();
+}
+
+// ---- nn.SpatialAveragePooling(2,2,2,2) (pwc.lua:155) on NHWC, float4 over channels ----
+__global__ void avgpool2_kernel(const float *in, int nimg, int H, int W, int C, float *out)
+{
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const size_t n = (size_t)nimg * Ho * Wo * C4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c4 = (int)(i % C4);
+    size_t pix = i / C4;
+    const int X = (int)(pix % Wo);
+    const size_t r = pix / Wo;
+    const int Y = (int)(r % Ho);
+    const size_t b = r / Ho;
+    const float4 *s = reinterpret_cast<const float4 *>(in) + ((b * H + 2 * Y) * W + 2 * X) * C4 + c4;
+    const float4 a = s[0], bb = s[C4], c = s[(size_t)W * C4], d = s[(size_t)(W + 1) * C4];
+    float4 o;
+    o.x = (a.x + bb.x + c.x + d.x) / 4.0f;
+    o.y = (a.y + bb.y + c.y + d.y) / 4.0f;
+    o.z = (a.z + bb.z + c.z + d.z) / 4.0f;
+    o.w = (a.w + bb.w + c.w + d.w) / 4.0f;
+    reinterpret_cast<float4 *>(out)[i] = o;
+}
+
+hipError_t launch_avgpool2_nhwc(const float *in, int nimg, int H, int W, int C, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)nimg * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, nimg, H, W, C, out);
+    return hipGetLastError();
+}
+
+// ---- layout changes at the API boundary (nn.Transpose({2,3},{3,4}) and back, pwc.lua:69-71) ----
+__global__ void nhwc_to_planar_kernel(const float *in, int pix_stride, int C, int B, int h, int w, float *out)
+{
+    const size_t hw = (size_t)h * w;
+    const size_t n = (size_t)B * C * hw;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t p = i % hw;
+    const size_t bc = i / hw;
+    const int c = (int)(bc % C);
+    const size_t b = bc / C;
+    out[i] = in[(b * hw + p) * pix_stride + c];
+}
+
+hipError_t launch_nhwc_to_planar(const float *in, int pix_stride, int C, int B, int h, int w, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * C * h * w;
+    hipLaunchKernelGGL(nhwc_to_planar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, pix_stride, C, B, h, w, out);
+    return hipGetLastError();
+}
+
+__global__ void planar_to_nhwc_kernel(const float *in, int C, int B, int h, int w, float *out, int pix_stride)
+{
+    const size_t hw = (size_t)h * w;
+    const size_t n = (size_t)B * hw * pix_stride;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % pix_stride);
+    const size_t bp = i / pix_stride;
+    const size_t p = bp % hw, b = bp / hw;
+    out[i] = c < C ? in[(b * C + c) * hw + p] : 0.f;
+}
+
+hipError_t launch_planar_to_nhwc(const float *in, int C, int B, int h, int w, float *out, int pix_stride, hipStream_t s)
+{
+    const size_t n = (size_t)B * h * w * pix_stride;
+    hipLaunchKernelGGL(planar_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, C, B, h, w, out, pix_stride);
+    return hipGetLastError();
+}
+
+__global__ void fill_kernel(float *p, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+hipError_t launch_fill(float *p, size_t n, float v, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+}  // namespace b2f

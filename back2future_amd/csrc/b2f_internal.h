@@ -1,0 +1,95 @@
+// Internal C++ interface between the C-ABI layer (b2f_api.hip) and the gfx950
+// kernels (b2f_conv.hip, b2f_corr.hip, b2f_glue.hip).  Device layout everywhere:
+// NHWC ("BHWD") fp32; see DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace b2f {
+
+// Architecture constants of the shipped graph (models/pwc.lua:29,76-89 with
+// opts.lua:83-98).
+constexpr int kLevels = 7, kLst = 3, kWin = 9, kND = 2 * kWin * kWin;  // 162
+constexpr int kFeat[8] = {0, 3, 16, 32, 64, 96, 128, 192};
+constexpr int kDec[7] = {0, 128, 128, 96, 64, 32, 2};
+// One cost-volume pixel record: [fwd 81 | bwd 81 | u | v] (u,v = the upsampled flow
+// that the decoders of pwc.lua:334 also take), 164 floats = 41 float4.
+constexpr int kCvRec = 164;
+constexpr int kImgC = 8;   // packed image channels (RGB + zero pad), one conv K-chunk
+constexpr int kCK = 8;     // conv K-chunk: input channels staged per LDS pass
+
+// ---- conv3x3 (MFMA implicit GEMM) -------------------------------------------------
+struct ConvSeg {
+    const float *ptr;   // NHWC base
+    long img_stride;    // floats between consecutive images
+    int pix_stride;     // floats between consecutive pixels
+    int nchunks;        // K-chunks (of kCK channels) taken from this segment
+};
+struct ConvLaunch {
+    ConvSeg seg[2];
+    int nseg;
+    const float *wpk;   // packed weights [nblk][chunk][9][2][NT*32][4]
+    const float *bias;  // [nblk*NT*32]
+    float *out;
+    long out_img_stride;
+    int out_pix_stride;
+    int cout;           // valid output channels
+    int nt, nblk;       // 32-wide N tiles per block, N blocks
+    int H, W, Ho, Wo, stride;
+    int nimg;
+    int leaky;
+};
+hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
+// floats needed for the packed weights of a conv with `cin_chunks` K-chunks
+size_t conv_wpk_floats(int cin_chunks, int nt, int nblk);
+void conv_choose_tiles(int cout, int *nt, int *nblk);
+// Host-side re-pack Co x Ci x 3 x 3 (Torch) -> kernel layout.  cin_map[k] gives, for
+// packed input channel k (0 .. chunks*8-1), the Torch input channel or -1 (zero).
+void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
+                       int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
+
+// ---- fused warp + cost volume -----------------------------------------------------
+struct CorrLaunch {
+    const float *ref, *nbr_fut, *nbr_past;  // NHWC, C channels
+    long img_stride;                         // floats per image for the three maps
+    int pix_stride;
+    const float *flow;                       // B x h x w x 2 or nullptr
+    float k;                                 // warp scale of the future frame (+k), past = -k
+    float *out;                              // B x h x w x kCvRec
+    int B, C, h, w;
+};
+hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);
+// generic (any odd win) single-direction cost volume, NHWC in, B x h x w x win*win out
+hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int C, int h, int w,
+                                  int win, int fwd, float *out, hipStream_t s);
+
+// ---- glue kernels -------------------------------------------------------------------
+// planar B x 9 x H x W -> 3 frame-major NHWC8 images ([3][B][H][W][8]), optional normalize
+hipError_t launch_pack_input(const float *in, int normalize, int B, int H, int W, float *img,
+                             hipStream_t s);
+// nn.BilinearSamplerBHWD forward (CUDA semantics), grid scaled by k
+hipError_t launch_warp_nhwc(const float *img, long img_stride, int pix_stride, int C, int ih,
+                            int iw, const float *grid, float k, int B, int gh, int gw,
+                            float *out, int out_pix_stride, hipStream_t s);
+// SpatialUpSamplingBilinear(2) on B x h x w x 2 -> B x 2h x 2w x 2
+hipError_t launch_upsample_flow2x(const float *in, int B, int h, int w, float *out, hipStream_t s);
+// second x2 + NHWC2 -> planar B x 2 x 2h x 2w
+hipError_t launch_upsample_flow2x_planar(const float *in, int B, int h, int w, float *out,
+                                         hipStream_t s);
+// softmax over 2 logits + nearest x4 -> planar B x 2 x 4h x 4w
+hipError_t launch_softmax_nearest4_planar(const float *logits, int B, int h, int w, float *out,
+                                          hipStream_t s);
+// warp full-res image 1 (packed NHWC8, RGB in ch 0..2) by k * planar flow -> planar B x 3 x H x W
+hipError_t launch_warp_image_planar(const float *img8, const float *flow_planar, float k, int B,
+                                    int H, int W, float *out, hipStream_t s);
+// 2x2 average pooling on NHWC (C multiple of 4)
+hipError_t launch_avgpool2_nhwc(const float *in, int nimg, int H, int W, int C, float *out,
+                                hipStream_t s);
+// NHWC (pix_stride, first C channels) -> planar B x C x h x w
+hipError_t launch_nhwc_to_planar(const float *in, int pix_stride, int C, int B, int h, int w,
+                                 float *out, hipStream_t s);
+hipError_t launch_planar_to_nhwc(const float *in, int C, int B, int h, int w, float *out,
+                                 int pix_stride, hipStream_t s);
+hipError_t launch_fill(float *p, size_t n, float v, hipStream_t s);
+
+}  // namespace b2f

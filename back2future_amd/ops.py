@@ -1,0 +1,60 @@
+"""Op-level calls through the C ABI, in the layouts of the reference modules
+(nn.CostVolMulti, nn.BilinearSamplerBHWD, nn.SpatialConvolution, ...).  Used by the parity
+tests; every call runs the HIP kernels of libb2f.so."""
+import numpy as np
+
+from . import _lib
+
+
+def _h(model):
+    return model._h
+
+
+def costvol(model, ref, frm, win=9, fwd=True):
+    ref, frm = _lib.f32(ref), _lib.f32(frm)
+    B, Cc, h, w = ref.shape
+    out = np.empty((B, win * win, h, w), np.float32)
+    _lib.check(_lib.lib().b2f_op_costvol(_h(model), _lib.fptr(ref), _lib.fptr(frm), B, Cc, h, w, win, int(bool(fwd)),
+                                         _lib.fptr(out)))
+    return out
+
+
+def warp_bhwd(model, img, grid):
+    img, grid = _lib.f32(img), _lib.f32(grid)
+    B, ih, iw, Cc = img.shape
+    _, gh, gw, _two = grid.shape
+    out = np.empty((B, gh, gw, Cc), np.float32)
+    _lib.check(_lib.lib().b2f_op_warp_bhwd(_h(model), _lib.fptr(img), _lib.fptr(grid), B, ih, iw, Cc, gh, gw,
+                                           _lib.fptr(out)))
+    return out
+
+
+def warp_costvol(model, ref, nbr_future, nbr_past, flow, k):
+    ref, nf, npast = _lib.f32(ref), _lib.f32(nbr_future), _lib.f32(nbr_past)
+    B, Cc, h, w = ref.shape
+    fl = _lib.f32(flow) if flow is not None else None
+    out = np.empty((B, 162, h, w), np.float32)
+    _lib.check(_lib.lib().b2f_op_warp_costvol(_h(model), _lib.fptr(ref), _lib.fptr(nf), _lib.fptr(npast),
+                                              _lib.fptr(fl) if fl is not None else None, float(k), B, Cc, h, w,
+                                              _lib.fptr(out)))
+    return out
+
+
+def conv3x3(model, x, w, b, stride=1, leaky=False):
+    x, w, b = _lib.f32(x), _lib.f32(w), _lib.f32(b)
+    B, ci, H, W = x.shape
+    co = w.shape[0]
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = np.empty((B, co, Ho, Wo), np.float32)
+    _lib.check(_lib.lib().b2f_op_conv3x3(_h(model), _lib.fptr(x), B, ci, H, W, _lib.fptr(w), _lib.fptr(b), co, stride,
+                                         int(bool(leaky)), _lib.fptr(y)))
+    return y
+
+
+def upsample_flow2x(model, x):
+    x = _lib.f32(x)
+    B, two, h, w = x.shape
+    assert two == 2
+    y = np.empty((B, 2, 2 * h, 2 * w), np.float32)
+    _lib.check(_lib.lib().b2f_op_upsample_flow2x(_h(model), _lib.fptr(x), B, h, w, _lib.fptr(y)))
+    return y

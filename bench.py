@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-triplets/sec of the computeFlow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A step = one pass of the whole computeFlow device pipeline
+(pack+normalize -> siamese feature pyramid -> 5 x (fused warp + cost volume -> flow decoder)
+-> occlusion decoder + softmax -> upsampling -> est[3]) over one batch of synthetic
+3 x 1024 x 1920 triplets that already sit in HBM (BASELINE.json configs[4]: 16 triplets per
+GPU).  Triplets are independent, so ranks share nothing in the timed region: the only
+collective is the RCCL broadcast of the flat weight buffer at start-up (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the task contract); `roofline` is the dominant kernel
+class (conv3x3 fp32-MFMA implicit GEMM), `roofline_corrwarp` the HBM-bound fused
+warp + cost-volume kernel that BASELINE.json's target is quoted on; both are timed live with
+HIP events on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/, kind "port") on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FEAT = [0, 3, 16, 32, 64, 96, 128, 192]
+DEC = [128, 128, 96, 64, 32, 2]
+
+
+def conv_flops_per_px():
+    """Algorithmic conv FLOPs (2*MAC) per full-resolution pixel of the pruned computeFlow
+    graph: features (3 frames) + flow decoders l=7..3 + occ decoder l=3."""
+    feat = sum(3 * 18 * (FEAT[l - 1] * FEAT[l] + FEAT[l] ** 2) / 4 ** (l - 1) for l in range(2, 8))
+
+    def dec(n):
+        ci, s = n, 0
+        for co in DEC:
+            s += 18 * ci * co
+            ci = co
+        return s
+    flow = sum(dec(162 if l == 7 else 162 + FEAT[l] + 2) / 4 ** (l - 1) for l in range(3, 8))
+    occ3 = dec(162 + FEAT[3] + 2) / 4 ** 2
+    return feat + flow + occ3
+
+
+def corr_bytes_per_px():
+    """Compulsory HBM bytes of the fused warp + cost volume per full-res pixel:
+    sum_l (3 C_l + 2 [l<7] + 162) * 4 / 4^(l-1) = 97.17."""
+    return sum((3 * FEAT[l] + (2 if l < 7 else 0) + 162) * 4 / 4 ** (l - 1) for l in range(3, 8))
+
+
+def make_triplets(torch, B, H, W, seed, device):
+    """im1 ~ U[0,1) smoothed by a 5x5 box, im2/im3 = im1 translated by (+3,+1)/(+6,+2) px plus
+    U(-0.02,0.02) noise (SURVEY s8d 'Synthetic inputs'), planar B x 9 x H x W in [0,1]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    base = torch.rand(B, 3, H + 16, W + 16, generator=g, device=device)
+    base = torch.nn.functional.avg_pool2d(base, 5, stride=1, padding=2)
+    out = torch.empty(B, 9, H, W, device=device)
+    for f, (dx, dy) in enumerate([(0, 0), (3, 1), (6, 2)]):
+        crop = base[:, :, 8 - dy:8 - dy + H, 8 - dx:8 - dx + W]
+        noise = (torch.rand(B, 3, H, W, generator=g, device=device) - 0.5) * 0.04
+        out[:, 3 * f:3 * f + 3] = (crop + noise).clamp_(0, 1)
+    return out.contiguous()
+
+
+def cpu_baseline(H, W, seed):
+    """Oracle (kind 'port') on the host cores, bounded sample: ONE triplet at H/2 x W/2."""
+    import numpy as np
+    from back2future_amd import weights as Wt
+    from oracle import oracle as O
+    h, w = H // 2, W // 2
+    rng = np.random.default_rng(seed)
+    x = rng.random((1, 9, h, w), dtype=np.float32)
+    params = Wt.random_init(2, False, 1.0)
+    O.lib()
+    t0 = time.perf_counter()
+    O.pwc_forward(x, params, False)
+    dt = time.perf_counter() - t0
+    frac = (h * w) / float(H * W)
+    return {"value": frac / dt, "unit": "triplets/s (3x%dx%d-equivalent pixels)" % (H, W),
+            "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 triplet at 3x%dx%d (1/4 of the pixels), full Ours-Hard graph, oracle/b2f_oracle.c "
+                      "with OpenMP on all host cores, %.2f s" % (h, w, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="triplets per GPU per step")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--graph", type=int, default=0, help="1: replay a captured hipGraph (no per-kernel events)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from back2future_amd import back2future
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the computeFlow path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, H, W = args.batch, args.height, args.width
+    model = back2future.Model("random:hard:2:1.0", device=local_rank)   # random-init pwc.lua weights, Ours-Hard shape
+    if world > 1:
+        # the one collective of the path: RCCL broadcast of the flat weight buffer (28.8 MB) from rank 0,
+        # replacing nn.DataParallelTable's NCCL parameter sync (util.lua:27-48)
+        from back2future_amd import dist as b2f_dist
+        b2f_dist.broadcast_weights(model, src=0)
+
+    x = make_triplets(torch, B, H, W, seed=2 + rank, device=dev)
+    flow = torch.empty(B, 2, H, W, device=dev)
+    occ = torch.empty(B, 2, H, W, device=dev)
+    est3 = torch.empty(B, 3, H, W, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        model.forward_device(x.data_ptr(), B, H, W, flow.data_ptr(), occ.data_ptr(), est3.data_ptr(),
+                             unit_input=True, stream=stream)
+
+    model.set_option("use_graph", args.graph)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    model.set_option("profile", 0 if args.graph else 1)
+    model.profile_reset()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = model.profile_read() if not args.graph else {}
+    finite = bool(torch.isfinite(flow).all().item() and torch.isfinite(occ).all().item())
+
+    if rank == 0:
+        px = H * W * B
+        out = {
+            "metric": "frame-triplets/sec at 3x%dx%d" % (H, W),
+            "value": world * B * args.steps / dt,
+            "unit": "triplets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4] per-GPU share: batch=%d synthetic 3x%dx%d triplets per "
+                                   "GPU, random-init pwc.lua weights (Ours-Hard shape), outputs flow + occ + est[3]"
+                                   % (B, H, W),
+                       "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
+                       "parallelism": "dp%d: independent triplets per rank, one RCCL weight broadcast at init" % world,
+                       "hip_graph": bool(args.graph)},
+            "outputs_finite": finite,
+        }
+        if prof:
+            conv_ms = sum(ms for k, (ms, n) in prof.items() if k.startswith("conv3x3")) / args.steps
+            conv_n = sum(n for k, (ms, n) in prof.items() if k.startswith("conv3x3")) / args.steps
+            corr_ms, corr_n = prof.get("warp_costvol", (0.0, 0))
+            corr_ms /= args.steps
+            corr_n /= args.steps
+            flops = conv_flops_per_px() * px
+            a = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            out["roofline"] = {"kernel": "conv3x3_mfma (all %d launches of a step)" % conv_n, "bound": "mfma",
+                               "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
+                               "traffic": None, "ms_per_step": conv_ms,
+                               "algorithmic_flop_per_step": flops}
+            cb = corr_bytes_per_px() * px
+            g = cb / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
+            out["roofline_corrwarp"] = {"kernel": "warp_costvol (%d launches of a step)" % corr_n, "bound": "hbm",
+                                        "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0,
+                                        "traffic": None, "ms_per_step": corr_ms,
+                                        "algorithmic_bytes_per_step": cb}
+            out["kernel_ms_per_step"] = {k: ms / args.steps for k, (ms, n) in sorted(prof.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, 2)
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/*
+ * b2f.h -- C ABI of libb2f.so: the MI355X-native (gfx950) drop-in for the
+ * back2future `init()` -> `computeFlow(im1, im2, im3)` hot path.
+ *
+ * The reference has no C ABI for this path: its native boundary is the Torch7
+ * Lua-C extension protocol (luaL_Reg tables on the tensor metatable,
+ * /root/reference/extras/stnbhwd/BilinearSamplerBHWD.cu:423-435, init.cu:11-18)
+ * and, above it, the Lua function pair exported by back2future.lua:45,97-130.
+ * Each entry point below cites the reference interface it replaces.  The
+ * LuaJIT-ffi / ctypes bindings that call this header are shown in
+ * INTEGRATION.md.
+ *
+ * Conventions: every call returns 0 on success, non-zero on error with a
+ * thread-local message readable through b2f_last_error() (the Lua shim turns
+ * it into error(msg), mirroring THError at BilinearSamplerBHWD.cu:151-156).
+ * Plain pointers and sizes only; the caller owns every buffer it passes in;
+ * the library owns device memory inside the opaque context.  A context is
+ * bound to one GPU (one process per GPU; multi-GPU = one context per rank with
+ * the flat weight buffer broadcast over RCCL by the host, see b2f_weights_device).
+ * "host" pointers are CPU memory, "dev" pointers are HIP device memory on the
+ * context's GPU.  `stream` is a hipStream_t passed as void* (NULL = the
+ * context's own stream).
+ */
+#ifndef B2F_H
+#define B2F_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define B2F_API __attribute__((visibility("default")))
+#else
+#define B2F_API
+#endif
+
+typedef struct b2f_ctx b2f_ctx;
+
+/* Error text of the last failing call on this thread ("" if none). */
+B2F_API const char *b2f_last_error(void);
+
+/* Library/ABI version (major*1000 + minor). */
+B2F_API int b2f_version(void);
+
+/* ---- life cycle: replaces back2future.init(opt) (back2future.lua:97-129) ----
+ * name_or_path:
+ *   "Ours-Hard" | "Ours-Soft-ft-KITTI" | "Ours-Soft-ft-Sintel"
+ *        -> models/RoamingImages_H.t7 | _H_KITTI_S.t7 | _H_Sintel_S.t7 relative to
+ *           the current directory, exactly as back2future.lua:100-110 (error if absent)
+ *   a path ending in ".t7"    -> Torch7 serialized nn.gModule / DataParallelTable
+ *   a path ending in ".b2fw"  -> flat fp32 blob in this repo's canonical order
+ *   "random:hard[:seed[:gain]]" | "random:soft[:seed[:gain]]"
+ *        -> the pwc.lua architecture with deterministic random weights
+ *           (nn.SpatialConvolution:reset() distribution), for synthetic benchmarks.
+ * device: HIP device ordinal.                                                    */
+B2F_API int b2f_init(const char *name_or_path, int device, b2f_ctx **out);
+B2F_API void b2f_destroy(b2f_ctx *ctx);
+
+/* levels (7), cost-volume window (9), past_flow (0 Hard / 1 Soft), number of
+ * tensors in the model:forward output table (20 / 25, pwc.lua:459-489), #params. */
+B2F_API int b2f_info(const b2f_ctx *ctx, int *levels, int *win, int *past_flow, int *n_outputs,
+             long long *n_params);
+
+/* ---- weights (the .t7 payload of back2future.lua:113) ----
+ * Canonical flat order: feature units l=2..7 {conv1.w,b,conv2.w,b};
+ * then l=7..3 {occ decoder, flow decoder, [past-flow decoder]} x 6 x {w,b};
+ * every w is Co x Ci x 3 x 3 as in nn.SpatialConvolution.                        */
+B2F_API long long b2f_param_count(int past_flow);
+/* Host-only, no GPU needed: fills out[n] with the deterministic random init. */
+B2F_API int b2f_random_weights(unsigned long long seed, int past_flow, float gain, float *out,
+                       long long n);
+B2F_API int b2f_set_weights(b2f_ctx *ctx, const float *host_flat, long long n);
+B2F_API int b2f_get_weights(b2f_ctx *ctx, float *host_flat, long long n);
+/* Device address of the flat canonical buffer, so that the host can broadcast it in
+ * place with RCCL (torch.distributed.broadcast) -- this replaces the NCCL parameter
+ * sync of nn.DataParallelTable (util.lua:27-48, train.lua:494-496).  Call
+ * b2f_commit_weights afterwards to rebuild the kernel-side packed copies.          */
+B2F_API int b2f_weights_device(b2f_ctx *ctx, void **dev_ptr, long long *n);
+B2F_API int b2f_commit_weights(b2f_ctx *ctx);
+/* Host-only .t7 reader (replaces torch.load + nngraph walk): fills out[n] in canonical
+ * order and sets *past_flow.  No GPU needed.                                       */
+B2F_API int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *past_flow);
+
+/* ---- the hot path, host boundary: computeFlow (back2future.lua:47-95) ----
+ * im1..im3: 3 x H0 x W0 planar RGB floats in [0,1] (what image.load returns).
+ * flow: 2 x H0 x W0 doubles (raw network flow, channel 0 = x, rescaled to H0 x W0
+ * exactly as :80-84);  fwd_occ / bwd_occ: H0 x W0 bytes (0/1), thresholds of
+ * est[3][2] / est[3][1] at 0.6666 (:87-91).                                        */
+B2F_API int b2f_compute_flow(b2f_ctx *ctx, const float *im1, const float *im2, const float *im3,
+                     int H0, int W0, double *flow, unsigned char *fwd_occ,
+                     unsigned char *bwd_occ);
+/* Same on n independent triplets (host buffers, n x 3 x H0 x W0 each frame set). */
+B2F_API int b2f_compute_flow_batch(b2f_ctx *ctx, int n, const float *im1, const float *im2,
+                           const float *im3, int H0, int W0, double *flow,
+                           unsigned char *fwd_occ, unsigned char *bwd_occ);
+
+/* ---- the hot path, device boundary: model:forward(imgs) (back2future.lua:74) ----
+ * dev_in: B x 9 x H x W planar fp32 on the GPU (the tensor `imgs` of :73), H and W
+ * multiples of 64.  in_kind: B2F_IN_NORMALIZED = already colour-normalized (what the
+ * reference feeds the model), B2F_IN_UNIT = raw [0,1] values, normalized on device.
+ * Outputs (any may be NULL), all planar fp32 on the GPU:
+ *   dev_flow  B x 2 x H x W   est[1] = skip_ufs[3]
+ *   dev_occ   B x 2 x H x W   skip_occs[3] (softmax probabilities)
+ *   dev_est3  B x C3 x H x W  est[3] as computeFlow reads it: C3 = 2 (Soft: the
+ *                             occlusion map) or 3 (Hard: warped image 1)
+ * The call is asynchronous on `stream`.                                            */
+enum { B2F_IN_NORMALIZED = 0, B2F_IN_UNIT = 1 };
+B2F_API int b2f_forward_device(b2f_ctx *ctx, const void *dev_in, int in_kind, int B, int H, int W,
+                       float *dev_flow, float *dev_occ, float *dev_est3, void *stream);
+/* Full output table of model:forward (pwc.lua:459-489) into n_outs host buffers, in
+ * table order; x is B x 9 x H x W normalized host memory.                           */
+B2F_API int b2f_forward(b2f_ctx *ctx, const float *x, int B, int H, int W, float **outs, int n_outs);
+B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh, int *ow, int cap);
+
+/* Execution options: use_graph = capture the forward into a hipGraph per shape and
+ * replay it; profile = record HIP events around every kernel launch (eager mode).   */
+B2F_API int b2f_set_option(b2f_ctx *ctx, const char *key, int value);
+/* Per-kernel-class timings gathered while profile=1.  names: cap x 32 chars.        */
+B2F_API int b2f_profile_read(b2f_ctx *ctx, char *names, double *total_ms, long long *launches,
+                     int cap, int *n);
+B2F_API int b2f_profile_reset(b2f_ctx *ctx);
+B2F_API int b2f_synchronize(b2f_ctx *ctx);
+
+/* ---- op-level entry points (host pointers, layouts of the reference modules) ----
+ * nn.CostVolMulti(win, fwd):updateOutput({ref, frm}) -- models/CostVolMulti.lua:49-109;
+ * ref, frm: B x C x h x w; out: B x win*win x h x w.                               */
+B2F_API int b2f_op_costvol(b2f_ctx *ctx, const float *ref, const float *frm, int B, int C, int h,
+                   int w, int win, int fwd, float *out);
+/* nn.BilinearSamplerBHWD:updateOutput({img, grid}), CUDA semantics --
+ * extras/stnbhwd/BilinearSamplerBHWD.cu:41-158; img: B x ih x iw x C, grid:
+ * B x gh x gw x 2 (x first), out: B x gh x gw x C.                                  */
+B2F_API int b2f_op_warp_bhwd(b2f_ctx *ctx, const float *img, const float *grid, int B, int ih,
+                     int iw, int C, int gh, int gw, float *out);
+/* The fused kernel the pipeline uses for pwc.lua:246-267 + :393-409: warp both
+ * neighbour maps by +k*flow (future) / -k*flow (past) and emit the joined
+ * 162-channel cost volume.  ref/nbr_future/nbr_past: B x C x h x w; flow: B x 2 x h x w
+ * or NULL (level 7: no warp); out: B x 162 x h x w.                                 */
+B2F_API int b2f_op_warp_costvol(b2f_ctx *ctx, const float *ref, const float *nbr_future,
+                        const float *nbr_past, const float *flow, float k, int B, int C,
+                        int h, int w, float *out);
+/* nn.SpatialConvolution(Ci,Co,3,3,s,s,1,1) [+ nn.LeakyReLU(0.2)] -- pwc.lua:58-85;
+ * x: B x Ci x H x W, w: Co x Ci x 3 x 3, y: B x Co x Ho x Wo.                       */
+B2F_API int b2f_op_conv3x3(b2f_ctx *ctx, const float *x, int B, int Ci, int H, int W, const float *w,
+                   const float *bias, int Co, int stride, int leaky, float *y);
+/* nn.SpatialUpSamplingBilinear(2) on a 2-channel flow field -- pwc.lua:360-381;
+ * x: B x 2 x h x w -> y: B x 2 x 2h x 2w.                                            */
+B2F_API int b2f_op_upsample_flow2x(b2f_ctx *ctx, const float *x, int B, int h, int w, float *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B2F_H */
