@@ -30,6 +30,7 @@
 namespace b2f {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: staging arrays of it stay in VGPRs
 
 template <int S, int TW>
 struct ConvGeom {
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     constexpr int A_PER_THREAD = G::A_PER_THREAD;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *ldsA = reinterpret_cast<float4 *>(smem);
-    float4 *ldsB = ldsA + G::A_F4;
+    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
+    f32x4 *ldsB = ldsA + G::A_F4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
 
     // ---- per-thread staging coordinates for the A patch (fixed over chunks) ----
-    int a_goff[A_PER_THREAD];   // float offset inside the image (pixel part), -1 = zero fill
+    int a_goff[A_PER_THREAD];   // pixel index inside the image (clamped to a valid pixel)
+    bool a_ok[A_PER_THREAD];    // false: halo outside the image / beyond the patch -> zero fill
     int a_lds[A_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
@@ -78,45 +80,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
         const int pix = idx >> 1, h = idx & 1;
         const int py = pix / PW, px = pix - py * PW;
         const int gy = iy0 + py, gx = ix0 + px;
-        const bool ok = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_goff[i] = ok ? (gy * p.W + gx) : -1;
+        a_ok[i] = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_goff[i] = a_ok[i] ? (gy * p.W + gx) : 0;   // unconditional load from a valid address, no branch
         a_lds[i] = (idx < G::A_F4) ? (h * NPIX + pix) : -1;
     }
     const int a_h4 = (tid & 1) * 4;
 
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
-    const float4 *wsrc = reinterpret_cast<const float4 *>(p.wpk) + (size_t)nb * nchunks * B_F4;
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * B_F4;
 
-    float4 ra[A_PER_THREAD], rb[B_PER_THREAD];
-    auto issue_loads = [&](int c) {
-        const bool s1 = c >= p.seg[0].nchunks;
-        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;
-        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;
-        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;
-        const int cc = s1 ? c - p.seg[0].nchunks : c;
-        const float *ib = base + (size_t)img * istr + cc * kCK + a_h4;
-#pragma unroll
-        for (int i = 0; i < A_PER_THREAD; ++i) {
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_goff[i] >= 0) ra[i] = *reinterpret_cast<const float4 *>(ib + (size_t)a_goff[i] * pstr);
-        }
-        const float4 *wb = wsrc + (size_t)c * B_F4;
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < B_F4) rb[i] = wb[idx];
-        }
-    };
-    auto write_lds = [&]() {
-#pragma unroll
-        for (int i = 0; i < A_PER_THREAD; ++i)
-            if (a_lds[i] >= 0) ldsA[a_lds[i]] = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < B_F4) ldsB[idx] = rb[i];
-        }
-    };
+    // Staging registers.  All loops below have compile-time trip counts and compile-time
+    // guards wherever a whole 256-thread pass fits (blockDim.x == 256 by construction), so the
+    // arrays stay in VGPRs and no load sits behind a divergent branch.
+    f32x4 ra[A_PER_THREAD], rb[B_PER_THREAD];
+#define B2F_ISSUE_LOADS(c_)                                                                         \
+    do {                                                                                            \
+        const int c__ = (c_);                                                                       \
+        const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
+        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
+        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
+        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;                            \
+        const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
+        const float *ib = base + (size_t)img * istr + cc * kCK + a_h4;                              \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
+            ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
+        const f32x4 *wb = wsrc + (size_t)c__ * B_F4;                                                \
+        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
+            if ((i + 1) * 256 <= B_F4) rb[i] = wb[tid + i * 256];                                   \
+            else rb[i] = wb[min(tid + i * 256, B_F4 - 1)];                                          \
+        }                                                                                           \
+    } while (0)
+#define B2F_WRITE_LDS()                                                                             \
+    do {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i) {                                  \
+            const f32x4 v = a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                            \
+            if ((i + 1) * 256 <= G::A_F4) ldsA[a_lds[i]] = v;                                       \
+            else if (a_lds[i] >= 0) ldsA[a_lds[i]] = v;                                             \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
+            if ((i + 1) * 256 <= B_F4) ldsB[tid + i * 256] = rb[i];                                 \
+            else if (tid + i * 256 < B_F4) ldsB[tid + i * 256] = rb[i];                             \
+        }                                                                                           \
+    } while (0)
 
     // ---- accumulators start at the bias (same order as y = b + sum in nn) ----
     f32x16 acc[NT];
@@ -130,19 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     // this lane's A pixel (M index m = lane & 31) inside the patch
     const int m_ty = (TW == 32) ? wave : (2 * wave + (n >> 4));
     const int m_tx = (TW == 32) ? n : (n & 15);
-    const float4 *aptr = ldsA + half * NPIX + (m_ty * S) * PW + m_tx * S;
-    const float4 *bptr = ldsB + half * NTOT + n;
+    const f32x4 *aptr = ldsA + half * NPIX + (m_ty * S) * PW + m_tx * S;
+    const f32x4 *bptr = ldsB + half * NTOT + n;
 
-    issue_loads(0);
+    B2F_ISSUE_LOADS(0);
     for (int c = 0; c < nchunks; ++c) {
-        write_lds();
+        B2F_WRITE_LDS();
         __syncthreads();
-        if (c + 1 < nchunks) issue_loads(c + 1);
+        if (c + 1 < nchunks) B2F_ISSUE_LOADS(c + 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const float4 a = aptr[ky * PW + kx];
-            float4 b[NT];
+            const f32x4 a = aptr[ky * PW + kx];
+            f32x4 b[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) b[t] = bptr[tap * 2 * NTOT + t * 32];
 #pragma unroll
@@ -242,5 +247,8 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
                         }
     for (int i = 0; i < nblk * ntot; ++i) bpk[i] = i < Co ? b[i] : 0.f;
 }
+
+#undef B2F_ISSUE_LOADS
+#undef B2F_WRITE_LDS
 
 }  // namespace b2f
