@@ -647,6 +647,9 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
         const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
+            // one eager pass first: kernels set their function attributes (dynamic LDS size) on
+            // first launch, which must not happen inside a stream capture
+            CHK(forward_impl(c, s, false, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3));
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int rc = forward_impl(c, s, true, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3);

@@ -7,8 +7,8 @@
 //
 // GEMM view: M = output pixels, N = output channels, K = 9 taps x Cin.
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles / 4096 FLOP.
-//   * block = 256 threads = 4 waves; block tile = 128 pixels (TH x TW) x NT*32 channels;
-//     wave w owns one 32-pixel M tile and all NT N tiles (NT <= 4 -> <= 64 acc VGPRs).
+//   * block = NW waves (8, or 4 for small maps); block tile = NW*32 pixels (TH x TW) x NT*32
+//     channels; wave w owns one 32-pixel M tile and all NT N tiles (NT <= 4 -> <= 64 acc VGPRs).
 //   * K is walked in chunks of 8 input channels.  Per chunk the block stages in LDS
 //       A: the input patch with halo, im2col done by address arithmetic at read time,
 //          laid out [k4 = 2][patch pixel] of float4 so that a half-wave reads 32
@@ -18,8 +18,9 @@
 //     Lane l = (n|m = l & 31, half = l >> 5).  For the 32x32x2 MFMA a lane supplies
 //     A[m][k = half] and B[k = half][n]; half h holds channels 4h..4h+3 of the chunk, so
 //     one b128 per operand feeds four consecutive MFMAs (k-pair j = {j, 4 + j}).
-//   * next chunk's global loads are issued before the MFMAs of the current one and
-//     written to LDS after it (register prefetch), two barriers per chunk.
+//   * two LDS buffers, ONE barrier per chunk: chunk c+1's global loads are issued before the
+//     MFMAs of chunk c, written to the other buffer right after them, then the barrier; the
+//     operands of tap t+1 are read from LDS before the 4*NT MFMAs of tap t.
 //   * input may come from up to two K segments (pointer, pixel stride, #chunks): the
 //     decoder's first layer reads {cs[ref][l], cost-volume record} without a JoinTable
 //     copy (pwc.lua:308,334).
@@ -27,34 +28,38 @@
 //     writes 32 consecutive channels of one pixel = 128 B).
 #include "b2f_internal.h"
 
+#include <cstdlib>
+
 namespace b2f {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: staging arrays of it stay in VGPRs
 
-template <int S, int TW>
+template <int S, int TW, int NW>
 struct ConvGeom {
-    static constexpr int TH = 128 / TW;
+    static constexpr int NTHR = NW * 64;
+    static constexpr int TH = NW * 32 / TW;
     static constexpr int PH = (TH - 1) * S + 3;
     static constexpr int PW = (TW - 1) * S + 3;
     static constexpr int NPIX = PH * PW;
     static constexpr int A_F4 = 2 * NPIX;                 // float4 slots of the A patch
-    static constexpr int A_PER_THREAD = (A_F4 + 255) / 256;
+    static constexpr int A_PER_THREAD = (A_F4 + NTHR - 1) / NTHR;
 };
 
-template <int S, int NT, int TW>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
+template <int S, int NT, int TW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
 {
-    using G = ConvGeom<S, TW>;
+    using G = ConvGeom<S, TW, NW>;
+    constexpr int NTHR = G::NTHR;
     constexpr int NPIX = G::NPIX, PW = G::PW;
     constexpr int NTOT = NT * 32;
     constexpr int B_F4 = 9 * 2 * NTOT;
-    constexpr int B_PER_THREAD = (B_F4 + 255) / 256;
+    constexpr int B_PER_THREAD = (B_F4 + NTHR - 1) / NTHR;
     constexpr int A_PER_THREAD = G::A_PER_THREAD;
+    constexpr int BUF_F4 = G::A_F4 + B_F4;                // one LDS buffer (A patch + B slab)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *ldsA = reinterpret_cast<f32x4 *>(smem);
-    f32x4 *ldsB = ldsA + G::A_F4;
+    f32x4 *lds = reinterpret_cast<f32x4 *>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     int a_lds[A_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTHR;
         const int pix = idx >> 1, h = idx & 1;
         const int py = pix / PW, px = pix - py * PW;
         const int gy = iy0 + py, gx = ix0 + px;
@@ -90,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * B_F4;
 
     // Staging registers.  All loops below have compile-time trip counts and compile-time
-    // guards wherever a whole 256-thread pass fits (blockDim.x == 256 by construction), so the
-    // arrays stay in VGPRs and no load sits behind a divergent branch.
+    // guards wherever a whole pass over the block fits, so the arrays stay in VGPRs and no
+    // load sits behind a divergent branch.
     f32x4 ra[A_PER_THREAD], rb[B_PER_THREAD];
 #define B2F_ISSUE_LOADS(c_)                                                                         \
     do {                                                                                            \
@@ -106,20 +111,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
             ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
         const f32x4 *wb = wsrc + (size_t)c__ * B_F4;                                                \
         _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
-            if ((i + 1) * 256 <= B_F4) rb[i] = wb[tid + i * 256];                                   \
-            else rb[i] = wb[min(tid + i * 256, B_F4 - 1)];                                          \
+            if ((i + 1) * NTHR <= B_F4) rb[i] = wb[tid + i * NTHR];                                 \
+            else rb[i] = wb[min(tid + i * NTHR, B_F4 - 1)];                                         \
         }                                                                                           \
     } while (0)
-#define B2F_WRITE_LDS()                                                                             \
+#define B2F_WRITE_LDS(buf_)                                                                         \
     do {                                                                                            \
+        f32x4 *la = lds + (buf_) * BUF_F4;                                                          \
+        f32x4 *lb = la + G::A_F4;                                                                   \
         _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i) {                                  \
             const f32x4 v = a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                            \
-            if ((i + 1) * 256 <= G::A_F4) ldsA[a_lds[i]] = v;                                       \
-            else if (a_lds[i] >= 0) ldsA[a_lds[i]] = v;                                             \
+            if ((i + 1) * NTHR <= G::A_F4) la[a_lds[i]] = v;                                        \
+            else if (a_lds[i] >= 0) la[a_lds[i]] = v;                                               \
         }                                                                                           \
         _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
-            if ((i + 1) * 256 <= B_F4) ldsB[tid + i * 256] = rb[i];                                 \
-            else if (tid + i * 256 < B_F4) ldsB[tid + i * 256] = rb[i];                             \
+            if ((i + 1) * NTHR <= B_F4) lb[tid + i * NTHR] = rb[i];                                 \
+            else if (tid + i * NTHR < B_F4) lb[tid + i * NTHR] = rb[i];                             \
         }                                                                                           \
     } while (0)
 
@@ -132,24 +139,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
         for (int r = 0; r < 16; ++r) acc[t][r] = bv;
     }
 
-    // this lane's A pixel (M index m = lane & 31) inside the patch
+    // this lane's A pixel (M index m = lane & 31) inside the patch: wave w owns patch rows
+    // w (TW == 32) or 2w, 2w+1 (TW == 16)
     const int m_ty = (TW == 32) ? wave : (2 * wave + (n >> 4));
     const int m_tx = (TW == 32) ? n : (n & 15);
-    const f32x4 *aptr = ldsA + half * NPIX + (m_ty * S) * PW + m_tx * S;
-    const f32x4 *bptr = ldsB + half * NTOT + n;
+    const int a_off = half * NPIX + (m_ty * S) * PW + m_tx * S;
+    const int b_off = G::A_F4 + half * NTOT + n;
 
     B2F_ISSUE_LOADS(0);
+    B2F_WRITE_LDS(0);
+    __syncthreads();
+    if (nchunks > 1) B2F_ISSUE_LOADS(1);
     for (int c = 0; c < nchunks; ++c) {
-        B2F_WRITE_LDS();
-        __syncthreads();
-        if (c + 1 < nchunks) B2F_ISSUE_LOADS(c + 1);
+        const f32x4 *aptr = lds + (c & 1) * BUF_F4 + a_off;
+        const f32x4 *bptr = lds + (c & 1) * BUF_F4 + b_off;
+        f32x4 a = aptr[0], b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = bptr[t * 32];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const f32x4 a = aptr[ky * PW + kx];
-            f32x4 b[NT];
+            f32x4 an = a, bn[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[t] = bptr[tap * 2 * NTOT + t * 32];
+            for (int t = 0; t < NT; ++t) bn[t] = b[t];
+            if (tap < 8) {   // operands of the next tap, in flight under this tap's MFMAs
+                const int ky = (tap + 1) / 3, kx = (tap + 1) - 3 * ky;
+                an = aptr[ky * PW + kx];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bn[t] = bptr[(tap + 1) * 2 * NTOT + t * 32];
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -158,9 +175,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+            a = an;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[t] = bn[t];
         }
-        __syncthreads();
+        if (c + 1 < nchunks) {
+            // buffer (c+1)&1 was last read during chunk c-1; every wave passed the barrier that
+            // closed iteration c-1 after finishing those reads, so it is free to overwrite now
+            B2F_WRITE_LDS((c + 1) & 1);
+            __syncthreads();
+            if (c + 2 < nchunks) B2F_ISSUE_LOADS(c + 2);
+        }
     }
+#undef B2F_ISSUE_LOADS
+#undef B2F_WRITE_LDS
 
     // ---- epilogue: C/D layout col = lane & 31 (cout), row = (r&3) + 8*(r>>2) + 4*half ----
     float *ob = p.out + (size_t)img * p.out_img_stride;
@@ -183,36 +211,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvLaunch p)
     }
 }
 
-template <int S, int NT, int TW>
+template <int S, int NT, int TW, int NW>
 static hipError_t launch_t(const ConvLaunch &p, hipStream_t s)
 {
-    using G = ConvGeom<S, TW>;
-    const size_t lds = sizeof(float4) * (G::A_F4 + 9 * 2 * NT * 32);
+    using G = ConvGeom<S, TW, NW>;
+    const size_t lds = 2 * sizeof(f32x4) * (G::A_F4 + 9 * 2 * NT * 32);
+    static bool attr_done = false;   // one flag per template instance
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_mfma<S, NT, TW, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::TH - 1) / G::TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * p.nimg), (unsigned)p.nblk);
-    hipLaunchKernelGGL((conv3x3_mfma<S, NT, TW>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv3x3_mfma<S, NT, TW, NW>), grid, dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
-template <int S, int TW>
+template <int S, int TW, int NW>
 static hipError_t launch_nt(const ConvLaunch &p, hipStream_t s)
 {
     switch (p.nt) {
-        case 1: return launch_t<S, 1, TW>(p, s);
-        case 2: return launch_t<S, 2, TW>(p, s);
-        case 3: return launch_t<S, 3, TW>(p, s);
-        case 4: return launch_t<S, 4, TW>(p, s);
+        case 1: return launch_t<S, 1, TW, NW>(p, s);
+        case 2: return launch_t<S, 2, TW, NW>(p, s);
+        case 3: return launch_t<S, 3, TW, NW>(p, s);
+        case 4: return launch_t<S, 4, TW, NW>(p, s);
     }
     return hipErrorInvalidValue;
 }
 
+// padded output area of a (TH x TW) tiling, used to pick the tile shape
+static long padded_area(int Ho, int Wo, int th, int tw)
+{
+    return (long)((Ho + th - 1) / th * th) * ((Wo + tw - 1) / tw * tw);
+}
+
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s)
 {
-    // 16-wide tiles for narrow maps (coarse pyramid levels), 32-wide otherwise
-    const bool narrow = (p.Wo <= 16) || (p.Wo % 32 != 0 && p.Wo % 32 <= 16 && p.Wo < 64);
-    if (p.stride == 1) return narrow ? launch_nt<1, 16>(p, s) : launch_nt<1, 32>(p, s);
-    if (p.stride == 2) return narrow ? launch_nt<2, 16>(p, s) : launch_nt<2, 32>(p, s);
-    return hipErrorInvalidValue;
+    if (p.stride != 1 && p.stride != 2) return hipErrorInvalidValue;
+    static const int force_nw = getenv("B2F_CONV_NW") ? atoi(getenv("B2F_CONV_NW")) : 0;
+    // candidates: 8 waves (8x32 or 16x16 pixels) for big maps, 4 waves (4x32 / 8x16) when the
+    // map is small (few blocks) or the 8-wave tiling wastes more than 1/8 of the MFMA work
+    const long a8_32 = padded_area(p.Ho, p.Wo, 8, 32), a8_16 = padded_area(p.Ho, p.Wo, 16, 16);
+    const long a4_32 = padded_area(p.Ho, p.Wo, 4, 32), a4_16 = padded_area(p.Ho, p.Wo, 8, 16);
+    const long best8 = a8_32 <= a8_16 ? a8_32 : a8_16, best4 = a4_32 <= a4_16 ? a4_32 : a4_16;
+    const long blocks8 = best8 / 256 * p.nimg * p.nblk;
+    bool use8 = blocks8 >= 512 && best8 * 8 <= best4 * 9;
+    if (force_nw == 4) use8 = false;
+    if (force_nw == 8) use8 = true;
+    if (use8) {
+        const bool w32 = a8_32 <= a8_16;
+        if (p.stride == 1) return w32 ? launch_nt<1, 32, 8>(p, s) : launch_nt<1, 16, 8>(p, s);
+        return w32 ? launch_nt<2, 32, 8>(p, s) : launch_nt<2, 16, 8>(p, s);
+    }
+    const bool w32 = a4_32 <= a4_16;
+    if (p.stride == 1) return w32 ? launch_nt<1, 32, 4>(p, s) : launch_nt<1, 16, 4>(p, s);
+    return w32 ? launch_nt<2, 32, 4>(p, s) : launch_nt<2, 16, 4>(p, s);
 }
 
 void conv_choose_tiles(int cout, int *nt, int *nblk)
@@ -247,8 +302,5 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
                         }
     for (int i = 0; i < nblk * ntot; ++i) bpk[i] = i < Co ? b[i] : 0.f;
 }
-
-#undef B2F_ISSUE_LOADS
-#undef B2F_WRITE_LDS
 
 }  // namespace b2f
