@@ -121,6 +121,23 @@ class Model(object):
             bwd.ctypes.data_as(C.POINTER(C.c_ubyte))))
         return flow, fwd, bwd
 
+    def output_shapes(self, H, W):
+        cap = 32
+        ch, oh, ow = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        _lib.check(_lib.lib().b2f_output_shapes(self._h, H, W, ch, oh, ow, cap))
+        return [(ch[i], oh[i], ow[i]) for i in range(self.n_outputs)]
+
+    def forward(self, x):
+        """model:forward(imgs) (back2future.lua:74): x is B x 9 x H x W, already normalized;
+        returns the whole output table of pwc.lua:459-489 as a list of B x C x h x w arrays."""
+        x = _lib.f32(x)
+        B, nine, H, W = x.shape
+        assert nine == 9
+        outs = [np.empty((B, c, h, w), np.float32) for (c, h, w) in self.output_shapes(H, W)]
+        ptrs = (_lib.c_float_p * len(outs))(*[_lib.fptr(o) for o in outs])
+        _lib.check(_lib.lib().b2f_forward(self._h, _lib.fptr(x), B, H, W, ptrs, len(outs)))
+        return outs
+
     def forward_device(self, d_in, B, H, W, d_flow=None, d_occ=None, d_est3=None, unit_input=False, stream=None):
         """model:forward on device pointers (ints); asynchronous on `stream`."""
         _lib.check(_lib.lib().b2f_forward_device(

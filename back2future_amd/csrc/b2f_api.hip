@@ -179,12 +179,14 @@ int pack_all(b2f_ctx *c, const float *flat)
             } else {
                 p.nseg = 1;
             }
-            const int rec_chunks = (kCvRec + kCK - 1) / kCK;   // 21
+            const int rec_chunks = (kCvRec + kCK - 1) / kCK;   // 21 chunks = 168 floats
             p.chunks[p.nseg - 1] = rec_chunks;
+            // record floats: 0..161 cost volume, 162,163 = ufs (future flow), 164,165 = ubfs (past flow)
+            const int flow_at = (d.kind == KIND_PAST) ? kND + 2 : kND;   // pwc.lua:334 vs :337
             for (int k = 0; k < rec_chunks * kCK; ++k) {
                 int ci = -1;
                 if (k < kND) ci = k;
-                else if (k < kND + 2 && has_flow) ci = kND + Cl + (k - kND);
+                else if (has_flow && k >= flow_at && k < flow_at + 2) ci = kND + Cl + (k - flow_at);
                 m.push_back(ci);
             }
         } else {
@@ -227,14 +229,18 @@ int find_conv(const b2f_ctx *c, int kind, int level, int idx)
 // ---- workspace -------------------------------------------------------------------------
 struct Plan {
     int B, H, W;
+    bool full;          // full model:forward table (all decoders, image pyramid, image warps)
+    int rec;            // cost-volume record size in floats
     int h[8], w[8];
-    size_t img, tmp, cs[8], U[8], cv, d[6], fs, logits, u2, flow_planar, total;
+    size_t img, tmp, cs[8], U[8], UB[8], cv, d[6], fs, bfs, logits, u2, flow_planar, ds[6], total;
 };
 
-Plan make_plan(int B, int H, int W)
+Plan make_plan(int B, int H, int W, bool full, bool past_flow)
 {
     Plan p;
     p.B = B; p.H = H; p.W = W;
+    p.full = full;
+    p.rec = (full && past_flow) ? kCvRecFull : kCvRec;
     for (int l = 1; l <= 7; ++l) { p.h[l] = H >> (l - 1); p.w[l] = W >> (l - 1); }
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
@@ -242,13 +248,17 @@ Plan make_plan(int B, int H, int W)
     p.tmp = take((size_t)3 * B * p.h[2] * p.w[2] * kFeat[2]);
     for (int l = 2; l <= 7; ++l) p.cs[l] = take((size_t)3 * B * p.h[l] * p.w[l] * kFeat[l]);
     for (int l = 3; l <= 6; ++l) p.U[l] = take((size_t)B * p.h[l] * p.w[l] * 2);
-    p.cv = take((size_t)B * p.h[3] * p.w[3] * kCvRec + 64);
+    for (int l = 3; l <= 6; ++l) p.UB[l] = (full && past_flow) ? take((size_t)B * p.h[l] * p.w[l] * 2) : 0;
+    p.cv = take((size_t)B * p.h[3] * p.w[3] * p.rec + 64);
     const size_t px3 = (size_t)B * p.h[3] * p.w[3];
     for (int i = 1; i <= 5; ++i) p.d[i] = take(px3 * kDec[i]);
     p.fs = take(px3 * 2);
+    p.bfs = take(px3 * 2);
     p.logits = take(px3 * 2);
     p.u2 = take(px3 * 4 * 2);
     p.flow_planar = take((size_t)B * 2 * H * W);
+    // image pyramid ds[f][k], f in {1,3}, k = 2..5 (pwc.lua:148-158): [2][B][H/2^(k-1)][W/2^(k-1)][8]
+    for (int k = 2; k <= 5; ++k) p.ds[k] = full ? take((size_t)2 * B * (H >> (k - 1)) * (W >> (k - 1)) * kImgC) : 0;
     p.total = off;
     return p;
 }
@@ -313,7 +323,7 @@ int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, in
     if (id1 < 0) return fail("decoder not present in this model");
     ConvSeg segs[2];
     const ConvSeg seg_ref = {A + P.cs[l] + (size_t)1 * B * hw * Cl, (long)(hw * Cl), Cl, 0};
-    const ConvSeg seg_cv = {A + P.cv, (long)(hw * kCvRec), kCvRec, 0};
+    const ConvSeg seg_cv = {A + P.cv, (long)(hw * P.rec), P.rec, 0};
     if (c->packed[id1].nseg == 2) { segs[0] = seg_ref; segs[1] = seg_cv; }
     else { segs[0] = seg_cv; segs[1] = seg_cv; }
     CHK(run_conv(c, s, cap, id1, segs, B, h, w, 1, 1, A + P.d[1], (long)(hw * kDec[1]), kDec[1]));
@@ -326,12 +336,21 @@ int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, in
     return 0;
 }
 
-// The pruned computeFlow graph (SURVEY.md Appendix B "live set").
-int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, const Plan &P,
-                 float *dev_flow, float *dev_occ, float *dev_est3)
+// Device outputs of one forward.  Pruned mode (computeFlow): flow / occ / est3 of the finest
+// level.  Full mode: the whole output table of pwc.lua:459-489, per level l = 3..7 (index l):
+// skip_ufs, skip_ubfs (Soft), skip_occs, iws[1], iws[3], all planar at 4h_l x 4w_l.
+struct Outs {
+    float *flow = nullptr, *occ = nullptr, *est3 = nullptr;
+    float *t_ufs[8] = {nullptr}, *t_ubfs[8] = {nullptr}, *t_occ[8] = {nullptr}, *t_iw1[8] = {nullptr}, *t_iw3[8] = {nullptr};
+};
+
+// The computeFlow graph: pruned to the live set or, with P.full, the
+// complete model:forward of models/pwc.lua.
+int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, const Plan &P, const Outs &O)
 {
     float *A = c->arena;
     const int B = P.B;
+    const bool full = P.full, past = c->past_flow && full;
     {
         Scope sc(c, s, "pack_input", cap);
         HIPCHK(launch_pack_input((const float *)dev_in, in_kind == B2F_IN_UNIT, B, P.H, P.W, A + P.img, s));
@@ -347,6 +366,21 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l],
                      (long)((size_t)ho * wo * Co), Co));
     }
+    if (full) {
+        // image pyramid of frames 1 and 3 for the warped-image outputs (pwc.lua:148-158);
+        // ds[k] holds [frame 1 | frame 3], level 1 is the packed input itself
+        Scope sc(c, s, "avgpool2", cap);
+        const size_t img_f = (size_t)B * P.H * P.W * kImgC;
+        for (int f = 0; f < 2; ++f) {
+            const float *src = A + P.img + (size_t)(f == 0 ? 0 : 2) * img_f;
+            for (int k = 2; k <= 5; ++k) {
+                const int hk = P.H >> (k - 2), wk = P.W >> (k - 2);
+                float *dst = A + P.ds[k] + (size_t)f * B * (hk / 2) * (wk / 2) * kImgC;
+                HIPCHK(launch_avgpool2_nhwc(src, B, hk, wk, kImgC, dst, s));
+                src = dst;
+            }
+        }
+    }
     for (int l = 7; l >= 3; --l) {   // pwc.lua:237
         const int h = P.h[l], w = P.w[l], Cl = kFeat[l];
         const size_t hw = (size_t)h * w;
@@ -357,38 +391,58 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.img_stride = (long)(hw * Cl);
         cl.pix_stride = Cl;
         cl.flow = (l < 7) ? A + P.U[l] : nullptr;
+        cl.flow_b = (l < 7 && past) ? A + P.UB[l] : nullptr;
         cl.k = (float)(20.0 / std::pow(2.0, l - 1));   // nn.MulConstant(20*(f-ref)/2^(l-2)) one level up, pwc.lua:404
         cl.out = A + P.cv;
+        cl.rec = P.rec;
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
         {
             Scope sc(c, s, "warp_costvol", cap);
             HIPCHK(launch_warp_costvol(cl, s));
         }
+        // occlusion decoder + SpatialSoftMax + nearest x4 (pwc.lua:288-321); dead below level 3 unless full
+        float *occ_out = full ? O.t_occ[l] : (l == 3 ? O.occ : nullptr);
+        float *occ_out2 = (!full && l == 3 && c->past_flow) ? O.est3 : nullptr;   // Soft: est[3] = skip_occs[3]
+        if (occ_out || occ_out2) {
+            CHK(run_decoder(c, s, cap, P, KIND_OCC, l, A + P.logits));
+            Scope sc(c, s, "softmax_nearest4", cap);
+            if (occ_out) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, h, w, occ_out, s));
+            if (occ_out2) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, h, w, occ_out2, s));
+        }
         CHK(run_decoder(c, s, cap, P, KIND_FLOW, l, A + P.fs));
-        if (l > 3) {
+        if (past) CHK(run_decoder(c, s, cap, P, KIND_PAST, l, A + P.bfs));
+        // upsampling (pwc.lua:359-390): ufs = bilinear x2; skip_ufs = a second bilinear x2
+        float *skip_f = full ? O.t_ufs[l] : (l == 3 ? (O.flow ? O.flow : A + P.flow_planar) : nullptr);
+        {
             Scope sc(c, s, "upsample_flow2x", cap);
-            HIPCHK(launch_upsample_flow2x(A + P.fs, B, h, w, A + P.U[l - 1], s));   // ufs[l], pwc.lua:360
+            float *u = (l > 3) ? A + P.U[l - 1] : A + P.u2;
+            HIPCHK(launch_upsample_flow2x(A + P.fs, B, h, w, u, s));
+            if (skip_f) HIPCHK(launch_upsample_flow2x_planar(u, B, 2 * h, 2 * w, skip_f, s));
+            if (past) {
+                // the past flow of level 3 has no next level: its x2 goes through the second half of u2's slot
+                float *ub = (l > 3) ? A + P.UB[l - 1] : A + P.d[1];
+                HIPCHK(launch_upsample_flow2x(A + P.bfs, B, h, w, ub, s));
+                if (O.t_ubfs[l]) HIPCHK(launch_upsample_flow2x_planar(ub, B, 2 * h, 2 * w, O.t_ubfs[l], s));
+            }
+        }
+        if (full) {
+            // warped images iws[f][l] = warp(ds[f][l-2], skip_u(b)fs[l] * 20(f-2)/2^(l-3))  (pwc.lua:422-446)
+            Scope sc(c, s, "warp_image", cap);
+            const int k = l - 2;   // pyramid level of the image (1 = full resolution)
+            const int hk = 4 * h, wk = 4 * w;
+            const size_t img_f = (size_t)B * hk * wk * kImgC;
+            const float *im1 = (k == 1) ? A + P.img : A + P.ds[k];
+            const float *im3 = (k == 1) ? A + P.img + 2 * img_f : A + P.ds[k] + img_f;
+            const float kk = (float)(20.0 / std::pow(2.0, l - 3));
+            const float *fl1 = (past && O.t_ubfs[l]) ? O.t_ubfs[l] : O.t_ufs[l];
+            if (O.t_iw1[l]) HIPCHK(launch_warp_image_planar(im1, fl1, -kk, B, hk, wk, O.t_iw1[l], s));
+            if (O.t_iw3[l]) HIPCHK(launch_warp_image_planar(im3, O.t_ufs[l], kk, B, hk, wk, O.t_iw3[l], s));
         }
     }
-    // finest level: skip_ufs[3] = two bilinear x2 (pwc.lua:359-390), occs[3] -> skip_occs[3]
-    float *flow_out = dev_flow ? dev_flow : A + P.flow_planar;
-    {
-        Scope sc(c, s, "upsample_flow2x", cap);
-        HIPCHK(launch_upsample_flow2x(A + P.fs, B, P.h[3], P.w[3], A + P.u2, s));
-        HIPCHK(launch_upsample_flow2x_planar(A + P.u2, B, P.h[2], P.w[2], flow_out, s));
-    }
-    const bool want_occ = dev_occ || (dev_est3 && c->past_flow);
-    if (want_occ) {
-        CHK(run_decoder(c, s, cap, P, KIND_OCC, 3, A + P.logits));
-        Scope sc(c, s, "softmax_nearest4", cap);
-        if (dev_occ) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, P.h[3], P.w[3], dev_occ, s));
-        if (dev_est3 && c->past_flow)   // Soft: est[3] = skip_occs[3]
-            HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, P.h[3], P.w[3], dev_est3, s));
-    }
-    if (dev_est3 && !c->past_flow) {
+    if (!full && O.est3 && !c->past_flow) {
         // Hard: est[3] = iws[1][3] = warp(I1, skip_ufs[3] * 20*(1-2)/2^0)  (pwc.lua:422-446,459-489)
         Scope sc(c, s, "warp_image", cap);
-        HIPCHK(launch_warp_image_planar(A + P.img, flow_out, -20.0f, B, P.H, P.W, dev_est3, s));
+        HIPCHK(launch_warp_image_planar(A + P.img, O.flow ? O.flow : A + P.flow_planar, -20.0f, B, P.H, P.W, O.est3, s));
     }
     return 0;
 }
@@ -641,18 +695,20 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
     CHK(check_shape(B, H, W));
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    const Plan P = make_plan(B, H, W);
+    const Plan P = make_plan(B, H, W, false, c->past_flow);
     CHK(ensure_workspace(c, P));
+    Outs O;
+    O.flow = dev_flow; O.occ = dev_occ; O.est3 = dev_est3;
     if (c->use_graph && !c->profile) {
         const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             // one eager pass first: kernels set their function attributes (dynamic LDS size) on
             // first launch, which must not happen inside a stream capture
-            CHK(forward_impl(c, s, false, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3));
+            CHK(forward_impl(c, s, false, dev_in, in_kind, P, O));
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = forward_impl(c, s, true, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3);
+            const int rc = forward_impl(c, s, true, dev_in, in_kind, P, O);
             const hipError_t e = hipStreamEndCapture(s, &g);
             if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
             HIPCHK(e);
@@ -664,7 +720,7 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
         HIPCHK(hipGraphLaunch(it->second, s));
         return 0;
     }
-    return forward_impl(c, s, false, dev_in, in_kind, P, dev_flow, dev_occ, dev_est3);
+    return forward_impl(c, s, false, dev_in, in_kind, P, O);
 }
 
 int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
@@ -745,9 +801,51 @@ int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow,
     return 0;
 }
 
-int b2f_forward(b2f_ctx *, const float *, int, int, int, float **, int)
+int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, int n_outs)
 {
-    return fail("b2f_forward: the full model:forward output table is not implemented yet (SURVEY s8f row 3)");
+    if (!c || !x || !outs) return fail("b2f_forward: null argument");
+    CHK(check_shape(B, H, W));
+    HIPCHK(hipSetDevice(c->device));
+    const int per = c->past_flow ? 5 : 4;
+    if (n_outs != (kLevels - kLst + 1) * per) return fail("b2f_forward: n_outs must be 20 (Hard) or 25 (Soft)");
+    // arena first (it may be re-allocated), then the per-output device buffers
+    const Plan P = make_plan(B, H, W, true, c->past_flow);
+    CHK(ensure_workspace(c, P));
+    std::vector<float *> dev(n_outs, nullptr);
+    std::vector<size_t> cnt(n_outs, 0);
+    float *d_in = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        for (float *p : dev) if (p) (void)hipFree(p);
+        if (d_in) (void)hipFree(d_in);
+    };
+    Outs O;
+    int no = 0;
+    for (int l = kLst; l <= kLevels && !rc; ++l) {
+        const size_t px = (size_t)B * P.h[l] * P.w[l] * 16;
+        for (int j = 0; j < per; ++j) {
+            const int ch = (j >= per - 2) ? 3 : 2;
+            cnt[no] = px * ch;
+            if (hipMalloc(&dev[no], cnt[no] * sizeof(float)) != hipSuccess) { rc = fail("b2f_forward: out of device memory"); break; }
+            ++no;
+        }
+        if (rc) break;
+        int base = (l - kLst) * per, j = 0;
+        O.t_ufs[l] = dev[base + j++];
+        if (c->past_flow) O.t_ubfs[l] = dev[base + j++];
+        O.t_occ[l] = dev[base + j++];
+        O.t_iw1[l] = dev[base + j++];
+        O.t_iw3[l] = dev[base + j++];
+    }
+    const size_t nin = (size_t)B * 9 * H * W;
+    if (!rc && hipMalloc(&d_in, nin * sizeof(float)) != hipSuccess) rc = fail("b2f_forward: out of device memory");
+    if (!rc && hipMemcpyAsync(d_in, x, nin * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail("b2f_forward: H2D copy failed");
+    if (!rc) rc = forward_impl(c, c->stream, false, d_in, B2F_IN_NORMALIZED, P, O);
+    for (int i = 0; i < n_outs && !rc; ++i)
+        if (hipMemcpyAsync(outs[i], dev[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail("b2f_forward: D2H copy failed");
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(std::string("b2f_forward: ") + hipGetErrorString(hipGetLastError()));
+    cleanup();
+    return rc;
 }
 
 // ---- op-level entry points (host pointers; reference module layouts) -----------------------
@@ -816,6 +914,8 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     cl.ref = dr.p; cl.nbr_fut = df.p; cl.nbr_past = dpa.p;
     cl.img_stride = (long)(hw * Cp); cl.pix_stride = Cp;
     cl.flow = flow ? dfl.p : nullptr;
+    cl.flow_b = nullptr;
+    cl.rec = kCvRec;
     cl.k = k; cl.out = dcv.p; cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
     HIPCHK(launch_warp_costvol(cl, c->stream));
     HIPCHK(launch_nhwc_to_planar(dcv.p, kCvRec, kND, B, h, w, dout.p, c->stream));

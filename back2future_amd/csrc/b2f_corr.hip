@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
     }
 
     if (!pvalid) return;
-    float *o = p.out + ((size_t)(b * p.h + py) * p.w + px) * kCvRec + dir * 81;
+    float *o = p.out + ((size_t)(b * p.h + py) * p.w + px) * p.rec + dir * 81;
     const float cf = (float)p.C, inv = 1.f / cf;
     if (dir == 0) {
 #pragma unroll
@@ -176,11 +176,18 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
     } else {
 #pragma unroll
         for (int c = 0; c < 81; ++c) o[80 - c] = POW2 ? acc[c] * inv : acc[c] / cf;
-        float2 f = make_float2(0.f, 0.f);
-        if (p.flow) f = *reinterpret_cast<const float2 *>(p.flow + ((size_t)(b * p.h + py) * p.w + px) * 2);
+        const size_t pix = (size_t)(b * p.h + py) * p.w + px;
+        float2 f = make_float2(0.f, 0.f), fb = make_float2(0.f, 0.f);
+        if (p.flow) f = *reinterpret_cast<const float2 *>(p.flow + pix * 2);
+        if (p.flow_b) fb = *reinterpret_cast<const float2 *>(p.flow_b + pix * 2);
         o[81] = f.x;
         o[82] = f.y;
-        if (b == p.B - 1 && py == p.h - 1 && px == p.w - 1) { o[83] = 0.f; o[84] = 0.f; o[85] = 0.f; o[86] = 0.f; }
+        // floats 164..167: (ub, vb, 0, 0) inside a 168-float record; for 164-float records they
+        // belong to the next pixel, except after the very last record, where the decoder's 21st
+        // K-chunk still reads them (with zero weights): keep them finite.
+        if (p.rec == kCvRecFull || (b == p.B - 1 && py == p.h - 1 && px == p.w - 1)) {
+            o[83] = fb.x; o[84] = fb.y; o[85] = 0.f; o[86] = 0.f;
+        }
     }
 }
 

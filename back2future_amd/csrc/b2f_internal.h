@@ -13,8 +13,12 @@ constexpr int kLevels = 7, kLst = 3, kWin = 9, kND = 2 * kWin * kWin;  // 162
 constexpr int kFeat[8] = {0, 3, 16, 32, 64, 96, 128, 192};
 constexpr int kDec[7] = {0, 128, 128, 96, 64, 32, 2};
 // One cost-volume pixel record: [fwd 81 | bwd 81 | u | v] (u,v = the upsampled flow
-// that the decoders of pwc.lua:334 also take), 164 floats = 41 float4.
+// that the decoders of pwc.lua:334 also take), 164 floats = 41 float4.  When the past-flow
+// decoders run too (full model:forward of a Soft model, pwc.lua:337) the record is
+// [fwd 81 | bwd 81 | u | v | ub | vb | 0 | 0] = 168 floats.  The decoders' first conv always
+// walks 21 K-chunks = 168 floats of it (zero weights beyond what the decoder takes).
 constexpr int kCvRec = 164;
+constexpr int kCvRecFull = 168;
 constexpr int kImgC = 8;   // packed image channels (RGB + zero pad), one conv K-chunk
 constexpr int kCK = 8;     // conv K-chunk: input channels staged per LDS pass
 
@@ -54,8 +58,10 @@ struct CorrLaunch {
     long img_stride;                         // floats per image for the three maps
     int pix_stride;
     const float *flow;                       // B x h x w x 2 or nullptr
+    const float *flow_b;                     // past flow ubfs (only copied into the record) or nullptr
     float k;                                 // warp scale of the future frame (+k), past = -k
-    float *out;                              // B x h x w x kCvRec
+    float *out;                              // B x h x w x rec
+    int rec;                                 // kCvRec or kCvRecFull
     int B, C, h, w;
 };
 hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);

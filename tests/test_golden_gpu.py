@@ -49,3 +49,17 @@ def test_forward_golden(kind):
     assert np.abs(occ.cpu().numpy() - g["out%02d" % occ_idx]).max() <= 1e-3
     assert np.abs(est3.cpu().numpy() - g["out02"]).max() <= 1e-3
     m.close()
+
+
+@pytest.mark.parametrize("kind", ["hard", "soft"])
+def test_full_output_table_golden(kind):
+    """b2f_forward: all 20 / 25 tensors of model:forward (pwc.lua:459-489) vs the witness."""
+    g = np.load(os.path.join(G, "forward_%s.npz" % kind))
+    m = back2future.Model("random:%s:%d:%g" % (kind, int(g["seed"]), float(g["gain"])))
+    outs = m.forward(g["x"])
+    assert len(outs) == (25 if kind == "soft" else 20)
+    for i, o in enumerate(outs):
+        exp = g["out%02d" % i]
+        assert o.shape == exp.shape
+        assert np.abs(o - exp).max() <= 1e-3, (i, float(np.abs(o - exp).max()))
+    m.close()

@@ -225,3 +225,17 @@ def test_errors_are_loud(hard):
     with pytest.raises(B2FError):
         hard.computeFlow(np.zeros((3, 32, 32), np.float32), np.zeros((3, 32, 32), np.float32),
                          np.zeros((3, 32, 32), np.float32))
+
+
+@pytest.mark.parametrize("which", ["hard", "soft"])
+def test_full_forward_table_vs_oracle(hard, soft, which):
+    """b2f_forward (full model:forward table) against the oracle at 128 x 192, batch 2."""
+    m = hard if which == "hard" else soft
+    r = _rng(31)
+    x = r.standard_normal((2, 9, 128, 192)).astype(np.float32)
+    outs = m.forward(x)
+    exp = O.pwc_forward(x, W.random_init(5, which == "soft", 2.0), which == "soft")
+    assert len(outs) == len(exp) == m.n_outputs
+    for i, (a, b) in enumerate(zip(outs, exp)):
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 1e-3, (i, float(np.abs(a - b).max()))
