@@ -62,6 +62,7 @@ struct CorrLaunch {
     float k;                                 // warp scale of the future frame (+k), past = -k
     float *out;                              // B x h x w x rec
     int rec;                                 // kCvRec or kCvRecFull
+    int ablate;                              // profiling only (B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores
     int B, C, h, w;
 };
 hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);
