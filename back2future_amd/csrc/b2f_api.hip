@@ -154,7 +154,7 @@ int prof_collect(b2f_ctx *c)
 // Builds, for every conv of the canonical layout, the K-order the kernels consume:
 //   features / inner decoder layers : input channels in order, zero padded to 8
 //   decoder layer 1                 : segment 0 = cs[ref][l] (C_l channels),
-//                                     segment 1 = cost-volume record [fwd 81|bwd 81|u|v|..]
+//                                     segment 1 = cost-volume record (slot order in b2f_internal.h)
 // while the Torch order of pwc.lua:308,334 is {cv 162, cs[ref][l] C_l, flow 2}.
 int pack_all(b2f_ctx *c, const float *flat)
 {
@@ -179,13 +179,15 @@ int pack_all(b2f_ctx *c, const float *flat)
             } else {
                 p.nseg = 1;
             }
-            const int rec_chunks = (kCvRec + kCK - 1) / kCK;   // 21 chunks = 168 floats
-            p.chunks[p.nseg - 1] = rec_chunks;
-            // record floats: 0..161 cost volume, 162,163 = ufs (future flow), 164,165 = ubfs (past flow)
-            const int flow_at = (d.kind == KIND_PAST) ? kND + 2 : kND;   // pwc.lua:334 vs :337
-            for (int k = 0; k < rec_chunks * kCK; ++k) {
+            p.chunks[p.nseg - 1] = kCvChunks;   // 21 chunks = 168 floats
+            // record slots: 0..79 fwd 0..79 | 80..159 bwd 0..79 | 160 fwd80 | 161 bwd80 | 162,163 ufs | 164,165 ubfs
+            const int flow_at = (d.kind == KIND_PAST) ? 164 : 162;   // pwc.lua:334 vs :337
+            for (int k = 0; k < kCvRec; ++k) {
                 int ci = -1;
-                if (k < kND) ci = k;
+                if (k < 80) ci = k;                       // fwd channel k      (Torch cv channel k)
+                else if (k < 160) ci = 81 + (k - 80);     // bwd channel k - 80 (Torch cv channel 81 + ..)
+                else if (k == 160) ci = 80;
+                else if (k == 161) ci = 161;
                 else if (has_flow && k >= flow_at && k < flow_at + 2) ci = kND + Cl + (k - flow_at);
                 m.push_back(ci);
             }
@@ -240,7 +242,7 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     Plan p;
     p.B = B; p.H = H; p.W = W;
     p.full = full;
-    p.rec = (full && past_flow) ? kCvRecFull : kCvRec;
+    p.rec = kCvRec;
     for (int l = 1; l <= 7; ++l) { p.h[l] = H >> (l - 1); p.w[l] = W >> (l - 1); }
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
@@ -252,9 +254,9 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     p.cv = take((size_t)B * p.h[3] * p.w[3] * p.rec + 64);
     const size_t px3 = (size_t)B * p.h[3] * p.w[3];
     for (int i = 1; i <= 5; ++i) p.d[i] = take(px3 * kDec[i]);
-    p.fs = take(px3 * 2);
-    p.bfs = take(px3 * 2);
-    p.logits = take(px3 * 2);
+    p.fs = take(px3 * 8);       // conv outputs are chunk-planar: 2 channels live in one 8-float chunk
+    p.bfs = take(px3 * 8);
+    p.logits = take(px3 * 8);
     p.u2 = take(px3 * 4 * 2);
     p.flow_planar = take((size_t)B * 2 * H * W);
     // image pyramid ds[f][k], f in {1,3}, k = 2..5 (pwc.lua:148-158): [2][B][H/2^(k-1)][W/2^(k-1)][8]
@@ -281,8 +283,20 @@ int ensure_workspace(b2f_ctx *c, const Plan &p)
 }
 
 // ---- one conv launch from the packed table -----------------------------------------------
+// All activations are chunk-planar: [image][C/8][h][w][8].
+ConvSeg cp8_seg(const float *ptr, int C, size_t hw)
+{
+    ConvSeg sgm;
+    sgm.ptr = ptr;
+    sgm.img_stride = (long)(hw * (size_t)((C + 7) / 8 * 8));
+    sgm.chunk_stride = (long)(hw * 8);
+    sgm.pix_stride = 8;
+    sgm.nchunks = 0;
+    return sgm;
+}
+
 int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *segs, int nimg, int H, int W,
-             int stride, int leaky, float *out, long out_img_stride, int out_pix_stride)
+             int stride, int leaky, float *out)
 {
     const PackedConv &p = c->packed[conv_id];
     ConvLaunch L;
@@ -295,14 +309,15 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.wpk = c->wpk_dev + p.w_off;
     L.bias = c->wpk_dev + p.b_off;
     L.out = out;
-    L.out_img_stride = out_img_stride;
-    L.out_pix_stride = out_pix_stride;
     L.cout = p.cout;
     L.nt = p.nt;
     L.nblk = p.nblk;
     L.H = H; L.W = W; L.stride = stride;
     L.Ho = (H + 2 - 3) / stride + 1;
     L.Wo = (W + 2 - 3) / stride + 1;
+    L.out_img_stride = (long)((size_t)L.Ho * L.Wo * ((p.cout + 7) / 8 * 8));
+    L.out_chunk_stride = (long)((size_t)L.Ho * L.Wo * 8);
+    L.out_pix_stride = 8;
     L.nimg = nimg;
     L.leaky = leaky;
     char name[32];
@@ -322,16 +337,15 @@ int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, in
     const int id1 = find_conv(c, kind, l, 1);
     if (id1 < 0) return fail("decoder not present in this model");
     ConvSeg segs[2];
-    const ConvSeg seg_ref = {A + P.cs[l] + (size_t)1 * B * hw * Cl, (long)(hw * Cl), Cl, 0};
-    const ConvSeg seg_cv = {A + P.cv, (long)(hw * P.rec), P.rec, 0};
+    const ConvSeg seg_ref = cp8_seg(A + P.cs[l] + (size_t)1 * B * hw * Cl, Cl, hw);
+    const ConvSeg seg_cv = cp8_seg(A + P.cv, kCvRec, hw);
     if (c->packed[id1].nseg == 2) { segs[0] = seg_ref; segs[1] = seg_cv; }
     else { segs[0] = seg_cv; segs[1] = seg_cv; }
-    CHK(run_conv(c, s, cap, id1, segs, B, h, w, 1, 1, A + P.d[1], (long)(hw * kDec[1]), kDec[1]));
+    CHK(run_conv(c, s, cap, id1, segs, B, h, w, 1, 1, A + P.d[1]));
     for (int i = 2; i <= 6; ++i) {
-        const ConvSeg in = {A + P.d[i - 1], (long)(hw * kDec[i - 1]), kDec[i - 1], 0};
+        const ConvSeg in = cp8_seg(A + P.d[i - 1], kDec[i - 1], hw);
         float *o = (i == 6) ? out2 : A + P.d[i];
-        const int oc = (i == 6) ? 2 : kDec[i];
-        CHK(run_conv(c, s, cap, find_conv(c, kind, l, i), &in, B, h, w, 1, i < 6, o, (long)(hw * oc), oc));
+        CHK(run_conv(c, s, cap, find_conv(c, kind, l, i), &in, B, h, w, 1, i < 6, o));
     }
     return 0;
 }
@@ -359,12 +373,10 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
     for (int l = 2; l <= 7; ++l) {
         const int hi = P.h[l - 1], wi = P.w[l - 1], ho = P.h[l], wo = P.w[l];
         const int Ci = (l == 2) ? kImgC : kFeat[l - 1], Co = kFeat[l];
-        const ConvSeg in1 = {(l == 2) ? A + P.img : A + P.cs[l - 1], (long)((size_t)hi * wi * Ci), Ci, 0};
-        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp,
-                     (long)((size_t)ho * wo * Co), Co));
-        const ConvSeg in2 = {A + P.tmp, (long)((size_t)ho * wo * Co), Co, 0};
-        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l],
-                     (long)((size_t)ho * wo * Co), Co));
+        const ConvSeg in1 = cp8_seg((l == 2) ? A + P.img : A + P.cs[l - 1], Ci, (size_t)hi * wi);
+        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp));
+        const ConvSeg in2 = cp8_seg(A + P.tmp, Co, (size_t)ho * wo);
+        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l]));
     }
     if (full) {
         // image pyramid of frames 1 and 3 for the warped-image outputs (pwc.lua:148-158);
@@ -389,12 +401,16 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.nbr_fut = A + P.cs[l] + (size_t)2 * B * hw * Cl;
         cl.nbr_past = A + P.cs[l];
         cl.img_stride = (long)(hw * Cl);
-        cl.pix_stride = Cl;
+        cl.chunk_stride = (long)(hw * 8);
+        cl.pix_stride = 8;
         cl.flow = (l < 7) ? A + P.U[l] : nullptr;
         cl.flow_b = (l < 7 && past) ? A + P.UB[l] : nullptr;
         cl.k = (float)(20.0 / std::pow(2.0, l - 1));   // nn.MulConstant(20*(f-ref)/2^(l-2)) one level up, pwc.lua:404
         cl.out = A + P.cv;
-        cl.rec = P.rec;
+        cl.out_img_stride = (long)(hw * kCvRec);
+        cl.out_chunk_stride = (long)(hw * 8);
+        cl.out_pix_stride = 8;
+        cl.ablate = 0;
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
         {
             Scope sc(c, s, "warp_costvol", cap);
@@ -406,8 +422,8 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         if (occ_out || occ_out2) {
             CHK(run_decoder(c, s, cap, P, KIND_OCC, l, A + P.logits));
             Scope sc(c, s, "softmax_nearest4", cap);
-            if (occ_out) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, h, w, occ_out, s));
-            if (occ_out2) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, B, h, w, occ_out2, s));
+            if (occ_out) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out, s));
+            if (occ_out2) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out2, s));
         }
         CHK(run_decoder(c, s, cap, P, KIND_FLOW, l, A + P.fs));
         if (past) CHK(run_decoder(c, s, cap, P, KIND_PAST, l, A + P.bfs));
@@ -416,13 +432,13 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         {
             Scope sc(c, s, "upsample_flow2x", cap);
             float *u = (l > 3) ? A + P.U[l - 1] : A + P.u2;
-            HIPCHK(launch_upsample_flow2x(A + P.fs, B, h, w, u, s));
-            if (skip_f) HIPCHK(launch_upsample_flow2x_planar(u, B, 2 * h, 2 * w, skip_f, s));
+            HIPCHK(launch_upsample_flow2x(A + P.fs, 8, B, h, w, u, s));
+            if (skip_f) HIPCHK(launch_upsample_flow2x_planar(u, 2, B, 2 * h, 2 * w, skip_f, s));
             if (past) {
                 // the past flow of level 3 has no next level: its x2 goes through the second half of u2's slot
                 float *ub = (l > 3) ? A + P.UB[l - 1] : A + P.d[1];
-                HIPCHK(launch_upsample_flow2x(A + P.bfs, B, h, w, ub, s));
-                if (O.t_ubfs[l]) HIPCHK(launch_upsample_flow2x_planar(ub, B, 2 * h, 2 * w, O.t_ubfs[l], s));
+                HIPCHK(launch_upsample_flow2x(A + P.bfs, 8, B, h, w, ub, s));
+                if (O.t_ubfs[l]) HIPCHK(launch_upsample_flow2x_planar(ub, 2, B, 2 * h, 2 * w, O.t_ubfs[l], s));
             }
         }
         if (full) {
@@ -882,7 +898,7 @@ int b2f_op_upsample_flow2x(b2f_ctx *c, const float *x, int B, int h, int w, floa
     CHK(dp.alloc(n)); CHK(dn.alloc(n)); CHK(dy.alloc(4 * n));
     HIPCHK(hipMemcpy(dp.p, x, n * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(launch_planar_to_nhwc(dp.p, 2, B, h, w, dn.p, 2, c->stream));
-    HIPCHK(launch_upsample_flow2x_planar(dn.p, B, h, w, dy.p, c->stream));
+    HIPCHK(launch_upsample_flow2x_planar(dn.p, 2, B, h, w, dy.p, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(y, dy.p, 4 * n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -895,9 +911,9 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     HIPCHK(hipSetDevice(c->device));
     const int Cp = (C + 7) / 8 * 8;   // the fused kernel walks channels in chunks of 8; zero channels add 0
     const size_t hw = (size_t)h * w, nplanar = (size_t)B * C * hw, nn = (size_t)B * hw * Cp;
-    DevBuf dpl, dr, df, dpa, dfl_pl, dfl, dcv, dout;
+    DevBuf dpl, dr, df, dpa, dfl_pl, dfl, dcv;
     CHK(dpl.alloc(nplanar)); CHK(dr.alloc(nn)); CHK(df.alloc(nn)); CHK(dpa.alloc(nn));
-    CHK(dcv.alloc((size_t)B * hw * kCvRec)); CHK(dout.alloc((size_t)B * kND * hw));
+    CHK(dcv.alloc((size_t)B * hw * kCvRec));
     const float *srcs[3] = {ref, nbr_future, nbr_past};
     float *dsts[3] = {dr.p, df.p, dpa.p};
     for (int i = 0; i < 3; ++i) {
@@ -912,19 +928,28 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     }
     CorrLaunch cl;
     cl.ref = dr.p; cl.nbr_fut = df.p; cl.nbr_past = dpa.p;
-    cl.img_stride = (long)(hw * Cp); cl.pix_stride = Cp;
+    cl.img_stride = (long)(hw * Cp); cl.chunk_stride = 8; cl.pix_stride = Cp;   // NHWC expressed with strides
     cl.flow = flow ? dfl.p : nullptr;
     cl.flow_b = nullptr;
-    cl.rec = kCvRec;
-    cl.k = k; cl.out = dcv.p; cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
+    cl.k = k; cl.out = dcv.p;
+    cl.out_img_stride = (long)(hw * kCvRec); cl.out_chunk_stride = 8; cl.out_pix_stride = kCvRec;
+    cl.ablate = 0;
+    cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
     HIPCHK(launch_warp_costvol(cl, c->stream));
-    HIPCHK(launch_nhwc_to_planar(dcv.p, kCvRec, kND, B, h, w, dout.p, c->stream));
+    std::vector<float> rec((size_t)B * hw * kCvRec);
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, dout.p, (size_t)B * kND * hw * sizeof(float), hipMemcpyDeviceToHost));
-    if (Cp != C) {   // the kernel divided by Cp; CostVolMulti.lua:100 divides by N = C
-        const size_t n = (size_t)B * kND * hw;
-        for (size_t i = 0; i < n; ++i) out[i] = out[i] * (float)Cp / (float)C;
-    }
+    HIPCHK(hipMemcpy(rec.data(), dcv.p, rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+    // record slots -> the reference's JoinTable order {fwd 81, bwd 81}; the kernel divided by Cp,
+    // CostVolMulti.lua:100 divides by N = C
+    const float fix = (Cp != C) ? (float)Cp / (float)C : 1.f;
+    for (int b = 0; b < B; ++b)
+        for (int d = 0; d < 2; ++d)
+            for (int ch = 0; ch < 81; ++ch) {
+                const int slot = cv_slot(d, ch);
+                float *dst = out + ((size_t)b * kND + d * 81 + ch) * hw;
+                const float *src = rec.data() + (size_t)b * hw * kCvRec + slot;
+                for (size_t i = 0; i < hw; ++i) dst[i] = src[i * kCvRec] * fix;
+            }
     return 0;
 }
 
@@ -979,11 +1004,11 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     HIPCHK(launch_planar_to_nhwc(dpl.p, Ci, B, H, W, dx.p, Cp, c->stream));
     ConvLaunch L;
     L.nseg = 1;
-    L.seg[0] = {dx.p, (long)((size_t)H * W * Cp), Cp, chunks};
+    L.seg[0] = {dx.p, (long)((size_t)H * W * Cp), 8, Cp, chunks};
     L.seg[1] = L.seg[0];
     L.seg[1].nchunks = 0;
     L.wpk = dw.p; L.bias = db.p; L.out = dy.p;
-    L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_pix_stride = Co; L.cout = Co;
+    L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_chunk_stride = 8; L.out_pix_stride = Co; L.cout = Co;
     L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
     HIPCHK(launch_conv3x3(L, c->stream));
     HIPCHK(launch_nhwc_to_planar(dy.p, Co, Co, B, Ho, Wo, dyp.p, c->stream));

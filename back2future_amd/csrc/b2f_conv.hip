@@ -21,11 +21,12 @@
 //   * two LDS buffers, ONE barrier per chunk: chunk c+1's global loads are issued before the
 //     MFMAs of chunk c, written to the other buffer right after them, then the barrier; the
 //     operands of tap t+1 are read from LDS before the 4*NT MFMAs of tap t.
-//   * input may come from up to two K segments (pointer, pixel stride, #chunks): the
-//     decoder's first layer reads {cs[ref][l], cost-volume record} without a JoinTable
-//     copy (pwc.lua:308,334).
-//   * epilogue: accumulators start at the bias, LeakyReLU fused, NHWC store (a half-wave
-//     writes 32 consecutive channels of one pixel = 128 B).
+//   * activations are chunk-planar ([image][C/8][h][w][8], b2f_internal.h): the 8-channel
+//     chunk of a patch row is one contiguous run, so the A loads are whole cache lines.
+//   * input may come from up to two K segments (pointer, strides, #chunks): the decoder's first
+//     layer reads {cs[ref][l], cost-volume record} without a JoinTable copy (pwc.lua:308,334).
+//   * epilogue: accumulators start at the bias, LeakyReLU fused, chunk-planar store (8 lanes
+//     write the 32-B chunk of one pixel; the four stores of 4 neighbouring pixels fill a line).
 #include "b2f_internal.h"
 
 #include <cstdlib>
@@ -104,9 +105,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
         const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
         const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
         const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
         const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;                            \
         const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
-        const float *ib = base + (size_t)img * istr + cc * kCK + a_h4;                              \
+        const float *ib = base + (size_t)img * istr + (size_t)cc * cstr + a_h4;                     \
         _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
             ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
         const f32x4 *wb = wsrc + (size_t)c__ * B_F4;                                                \
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
             if (oy < p.Ho && ox < p.Wo) {
                 float v = acc[t][r];
                 if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-                ob[(size_t)(oy * p.Wo + ox) * p.out_pix_stride + co] = v;
+                ob[(size_t)(co >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co & 7)] = v;
             }
         }
     }

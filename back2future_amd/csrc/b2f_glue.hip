@@ -89,7 +89,7 @@ hipError_t launch_warp_nhwc(const float *img, long img_stride, int pix_stride, i
 
 // ---- nn.SpatialUpSamplingBilinear(2.0) on a 2-channel flow field (pwc.lua:360-381):
 // align-corners ratios, h1 = (int)(r*h2), lambda = r*h2 - h1, h1p = h1 < h-1. ----
-__device__ __forceinline__ float2 bilerp2(const float2 *in, int h, int w, float rh, float rw, int y2, int x2)
+__device__ __forceinline__ float2 bilerp2(const float *in, int ps, int h, int w, float rh, float rw, int y2, int x2)
 {
     const float h1r = rh * (float)y2;
     const int h1 = (int)h1r;
@@ -99,15 +99,17 @@ __device__ __forceinline__ float2 bilerp2(const float2 *in, int h, int w, float 
     const int w1 = (int)w1r;
     const int w1p = (w1 < w - 1) ? 1 : 0;
     const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-    const float2 *p = in + (size_t)h1 * w + w1;
-    const float2 a = p[0], b = p[w1p], c = p[(size_t)h1p * w], d = p[(size_t)h1p * w + w1p];
+    const float *p = in + ((size_t)h1 * w + w1) * ps;
+    const float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(p + (size_t)w1p * ps);
+    const float2 c = *reinterpret_cast<const float2 *>(p + (size_t)h1p * w * ps);
+    const float2 d = *reinterpret_cast<const float2 *>(p + ((size_t)h1p * w + w1p) * ps);
     float2 o;
     o.x = h0l * (w0l * a.x + w1l * b.x) + h1l * (w0l * c.x + w1l * d.x);
     o.y = h0l * (w0l * a.y + w1l * b.y) + h1l * (w0l * c.y + w1l * d.y);
     return o;
 }
 
-__global__ void upsample_flow2x_kernel(const float *in, int B, int h, int w, float *out, int planar)
+__global__ void upsample_flow2x_kernel(const float *in, int ps, int B, int h, int w, float *out, int planar)
 {
     const int H2 = 2 * h, W2 = 2 * w;
     const size_t n = (size_t)B * H2 * W2;
@@ -119,7 +121,7 @@ __global__ void upsample_flow2x_kernel(const float *in, int B, int h, int w, flo
     const int b = (int)(r / H2);
     const float rh = (H2 > 1) ? (float)(h - 1) / (float)(H2 - 1) : 0.f;
     const float rw = (W2 > 1) ? (float)(w - 1) / (float)(W2 - 1) : 0.f;
-    const float2 o = bilerp2(reinterpret_cast<const float2 *>(in) + (size_t)b * h * w, h, w, rh, rw, y2, x2);
+    const float2 o = bilerp2(in + (size_t)b * h * w * ps, ps, h, w, rh, rw, y2, x2);
     if (planar) {
         const size_t hw2 = (size_t)H2 * W2;
         out[((size_t)b * 2) * hw2 + (size_t)y2 * W2 + x2] = o.x;
@@ -129,23 +131,23 @@ __global__ void upsample_flow2x_kernel(const float *in, int B, int h, int w, flo
     }
 }
 
-hipError_t launch_upsample_flow2x(const float *in, int B, int h, int w, float *out, hipStream_t s)
+hipError_t launch_upsample_flow2x(const float *in, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
 {
     const size_t n = (size_t)B * 4 * h * w;
-    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, h, w, out, 0);
+    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_pix_stride, B, h, w, out, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_upsample_flow2x_planar(const float *in, int B, int h, int w, float *out, hipStream_t s)
+hipError_t launch_upsample_flow2x_planar(const float *in, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
 {
     const size_t n = (size_t)B * 4 * h * w;
-    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, h, w, out, 1);
+    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_pix_stride, B, h, w, out, 1);
     return hipGetLastError();
 }
 
 // ---- nn.SpatialSoftMax over the 2 decoder logits (pwc.lua:308) + two
 // nn.SpatialUpSamplingNearest(2) (pwc.lua:311-321) -> planar B x 2 x 4h x 4w. ----
-__global__ void softmax_nearest4_kernel(const float *logits, int B, int h, int w, float *out)
+__global__ void softmax_nearest4_kernel(const float *logits, int ps, int B, int h, int w, float *out)
 {
     const int H4 = 4 * h, W4 = 4 * w;
     const size_t n = (size_t)B * H4 * W4;
@@ -155,7 +157,7 @@ __global__ void softmax_nearest4_kernel(const float *logits, int B, int h, int w
     const size_t r = i / W4;
     const int Y = (int)(r % H4);
     const int b = (int)(r / H4);
-    const float2 z = reinterpret_cast<const float2 *>(logits)[((size_t)b * h + Y / 4) * w + X / 4];
+    const float2 z = *reinterpret_cast<const float2 *>(logits + (((size_t)b * h + Y / 4) * w + X / 4) * ps);
     const float m = fmaxf(z.x, z.y);
     const float e0 = expf(z.x - m), e1 = expf(z.y - m);
     const float sum = e0 + e1;
@@ -164,10 +166,10 @@ __global__ void softmax_nearest4_kernel(const float *logits, int B, int h, int w
     out[((size_t)b * 2 + 1) * hw4 + (size_t)Y * W4 + X] = e1 / sum;
 }
 
-hipError_t launch_softmax_nearest4_planar(const float *logits, int B, int h, int w, float *out, hipStream_t s)
+hipError_t launch_softmax_nearest4_planar(const float *logits, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
 {
     const size_t n = (size_t)B * 16 * h * w;
-    hipLaunchKernelGGL(softmax_nearest4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, B, h, w, out);
+    hipLaunchKernelGGL(softmax_nearest4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, in_pix_stride, B, h, w, out);
     return hipGetLastError();
 }
 
@@ -254,6 +256,27 @@ hipError_t launch_nhwc_to_planar(const float *in, int pix_stride, int C, int B, 
 {
     const size_t n = (size_t)B * C * h * w;
     hipLaunchKernelGGL(nhwc_to_planar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, pix_stride, C, B, h, w, out);
+    return hipGetLastError();
+}
+
+__global__ void cp8_to_planar_kernel(const float *in, int C, int B, int h, int w, float *out)
+{
+    const size_t hw = (size_t)h * w;
+    const size_t n = (size_t)B * C * hw;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t p = i % hw;
+    const size_t bc = i / hw;
+    const int c = (int)(bc % C);
+    const size_t b = bc / C;
+    const int nch = (C + 7) / 8;
+    out[i] = in[((b * nch + (c >> 3)) * hw + p) * 8 + (c & 7)];
+}
+
+hipError_t launch_cp8_to_planar(const float *in, int C, int B, int h, int w, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * C * h * w;
+    hipLaunchKernelGGL(cp8_to_planar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, C, B, h, w, out);
     return hipGetLastError();
 }
 

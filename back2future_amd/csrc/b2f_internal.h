@@ -12,20 +12,27 @@ namespace b2f {
 constexpr int kLevels = 7, kLst = 3, kWin = 9, kND = 2 * kWin * kWin;  // 162
 constexpr int kFeat[8] = {0, 3, 16, 32, 64, 96, 128, 192};
 constexpr int kDec[7] = {0, 128, 128, 96, 64, 32, 2};
-// One cost-volume pixel record: [fwd 81 | bwd 81 | u | v] (u,v = the upsampled flow
-// that the decoders of pwc.lua:334 also take), 164 floats = 41 float4.  When the past-flow
-// decoders run too (full model:forward of a Soft model, pwc.lua:337) the record is
-// [fwd 81 | bwd 81 | u | v | ub | vb | 0 | 0] = 168 floats.  The decoders' first conv always
-// walks 21 K-chunks = 168 floats of it (zero weights beyond what the decoder takes).
-constexpr int kCvRec = 164;
-constexpr int kCvRecFull = 168;
+// Activation layout on the device: "chunk-planar" fp32, [image][C/8][h][w][8] -- planes of
+// 8-channel chunks.  An 8-channel chunk is the K step of the conv kernel and of the cost-volume
+// kernel, and in this layout the chunk of neighbouring pixels is contiguous (32 B per pixel, four
+// pixels per 128-B line), so halo tiles and bilinear gathers touch whole cache lines instead of
+// 32 B out of every pixel's NHWC record.  Kernels take (img_stride, chunk_stride, pix_stride) in
+// floats, so NHWC is still expressible (chunk_stride = 8, pix_stride = C) for the op-level API.
+//
+// One cost-volume pixel record = 21 chunks = 168 floats, slot order
+//   [fwd 0..79 | bwd 0..79 | fwd80, bwd80, u, v, ub, vb, 0, 0]
+// (u,v = ufs[l+1], ub,vb = ubfs[l+1]: the upsampled flows the decoders also take, pwc.lua:334,337).
+// Each direction's first 80 channels fill ten whole chunks, so a thread stores float4 pairs.
+constexpr int kCvRec = 168;
+constexpr int kCvChunks = 21;
 constexpr int kImgC = 8;   // packed image channels (RGB + zero pad), one conv K-chunk
 constexpr int kCK = 8;     // conv K-chunk: input channels staged per LDS pass
 
 // ---- conv3x3 (MFMA implicit GEMM) -------------------------------------------------
 struct ConvSeg {
-    const float *ptr;   // NHWC base
+    const float *ptr;
     long img_stride;    // floats between consecutive images
+    long chunk_stride;  // floats between consecutive 8-channel chunks of one pixel
     int pix_stride;     // floats between consecutive pixels
     int nchunks;        // K-chunks (of kCK channels) taken from this segment
 };
@@ -36,6 +43,7 @@ struct ConvLaunch {
     const float *bias;  // [nblk*NT*32]
     float *out;
     long out_img_stride;
+    long out_chunk_stride;
     int out_pix_stride;
     int cout;           // valid output channels
     int nt, nblk;       // 32-wide N tiles per block, N blocks
@@ -54,17 +62,20 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
 
 // ---- fused warp + cost volume -----------------------------------------------------
 struct CorrLaunch {
-    const float *ref, *nbr_fut, *nbr_past;  // NHWC, C channels
-    long img_stride;                         // floats per image for the three maps
+    const float *ref, *nbr_fut, *nbr_past;  // C channels each
+    long img_stride, chunk_stride;           // of the three maps
     int pix_stride;
-    const float *flow;                       // B x h x w x 2 or nullptr
+    const float *flow;                       // B x h x w x 2 (ufs) or nullptr
     const float *flow_b;                     // past flow ubfs (only copied into the record) or nullptr
     float k;                                 // warp scale of the future frame (+k), past = -k
-    float *out;                              // B x h x w x rec
-    int rec;                                 // kCvRec or kCvRecFull
-    int ablate;                              // profiling only (B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores
+    float *out;                              // records, kCvRec floats per pixel
+    long out_img_stride, out_chunk_stride;
+    int out_pix_stride;
     int B, C, h, w;
+    int ablate;                              // profiling only (B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
 };
+// slot of cost-volume channel c (0..80) of direction dir (0 fwd, 1 bwd) inside a record
+inline int cv_slot(int dir, int c) { return c < 80 ? dir * 80 + c : 160 + dir; }
 hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);
 // generic (any odd win) single-direction cost volume, NHWC in, B x h x w x win*win out
 hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int C, int h, int w,
@@ -78,14 +89,16 @@ hipError_t launch_pack_input(const float *in, int normalize, int B, int H, int W
 hipError_t launch_warp_nhwc(const float *img, long img_stride, int pix_stride, int C, int ih,
                             int iw, const float *grid, float k, int B, int gh, int gw,
                             float *out, int out_pix_stride, hipStream_t s);
-// SpatialUpSamplingBilinear(2) on B x h x w x 2 -> B x 2h x 2w x 2
-hipError_t launch_upsample_flow2x(const float *in, int B, int h, int w, float *out, hipStream_t s);
-// second x2 + NHWC2 -> planar B x 2 x 2h x 2w
-hipError_t launch_upsample_flow2x_planar(const float *in, int B, int h, int w, float *out,
-                                         hipStream_t s);
-// softmax over 2 logits + nearest x4 -> planar B x 2 x 4h x 4w
-hipError_t launch_softmax_nearest4_planar(const float *logits, int B, int h, int w, float *out,
-                                          hipStream_t s);
+// SpatialUpSamplingBilinear(2) on a 2-channel field stored with `in_pix_stride` floats per pixel
+// (2 = packed, 8 = first two channels of a chunk) -> packed B x 2h x 2w x 2
+hipError_t launch_upsample_flow2x(const float *in, int in_pix_stride, int B, int h, int w, float *out,
+                                  hipStream_t s);
+// second x2 + packed -> planar B x 2 x 2h x 2w
+hipError_t launch_upsample_flow2x_planar(const float *in, int in_pix_stride, int B, int h, int w,
+                                         float *out, hipStream_t s);
+// softmax over 2 logits (first two floats of each `in_pix_stride` record) + nearest x4 -> planar
+hipError_t launch_softmax_nearest4_planar(const float *logits, int in_pix_stride, int B, int h, int w,
+                                          float *out, hipStream_t s);
 // warp full-res image 1 (packed NHWC8, RGB in ch 0..2) by k * planar flow -> planar B x 3 x H x W
 hipError_t launch_warp_image_planar(const float *img8, const float *flow_planar, float k, int B,
                                     int H, int W, float *out, hipStream_t s);
@@ -95,6 +108,8 @@ hipError_t launch_avgpool2_nhwc(const float *in, int nimg, int H, int W, int C, 
 // NHWC (pix_stride, first C channels) -> planar B x C x h x w
 hipError_t launch_nhwc_to_planar(const float *in, int pix_stride, int C, int B, int h, int w,
                                  float *out, hipStream_t s);
+// chunk-planar [B][C/8][h][w][8] -> planar B x C x h x w
+hipError_t launch_cp8_to_planar(const float *in, int C, int B, int h, int w, float *out, hipStream_t s);
 hipError_t launch_planar_to_nhwc(const float *in, int C, int B, int h, int w, float *out,
                                  int pix_stride, hipStream_t s);
 hipError_t launch_fill(float *p, size_t n, float v, hipStream_t s);
