@@ -1,12 +1,363 @@
-// Placeholder until the Torch7 .t7 reader lands.
+// Torch7 ".t7" reader for the shipped multi-frame PWC models: replaces `torch.load(modelPath)`
+// + `model:get(1)` of /root/reference/back2future.lua:113-116 without Lua/Torch.
+//
+// [3P] The binary serialization format lives in torch7 (File.lua, not in the reference tree);
+// restated from its published behaviour: little endian; every object starts with an int32 type
+// tag {0 nil, 1 number (double), 2 string (int32 len + bytes), 3 table, 4 torch object,
+// 5 boolean (int32), 6/7/8 function}; tables, torch objects and functions carry an int32
+// reference index (an index seen before = the same object again -- this is how the siamese
+// clones of pwc.lua:187-195 share one storage); a torch object is a version string "V 1", a class
+// name, then either a class-specific payload (Tensor: int32 nDim, int64 size[], int64 stride[],
+// int64 1-based storageOffset, storage object; Storage: int64 n + raw elements; Cuda* classes
+// use the float/.. payload of their CPU twins) or, for every nn.* / cudnn.* / nngraph.* /
+// graph.* object, a table of its fields.
+// No .t7 file exists in the reference tree (the three models are Dropbox links, README.md:49-52),
+// so this reader is validated against a writer that produces the same structures
+// (tests/t7_writer.py), not against a real file: see DESIGN.md.
+//
+// Role recovery: the gModule's forward nodes are walked; nn.Sequential
+// modules with 2 convolutions are the convUnits (level from nInputPlane -> nOutputPlane), with 6
+// convolutions decoders (level from the first nInputPlane: 354/162 -> 7, 292, 260, 228, 196 -> 6..3).
+// Decoders of one level have identical shapes, so the role comes from the graph: consumer is a
+// SpatialSoftMax -> occlusion decoder; otherwise the MulConstant nodes reachable through the
+// up-sampling chain decide: a positive constant (20*(3-2)/2^k, pwc.lua:404,443) -> future flow,
+// only negative ones -> past flow.
 #include "b2f_host.h"
 
-namespace b2f {
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
 
-bool load_t7(const std::string &path, std::vector<float> &, bool &, std::string &err)
+namespace b2f {
+namespace {
+
+struct Obj;
+typedef std::shared_ptr<Obj> Ref;
+
+struct Obj {
+    enum Kind { NIL, NUM, STR, BOOL, TABLE, TORCH, TENSOR, STORAGE, FUNC } kind = NIL;
+    double num = 0;
+    bool b = false;
+    std::string str;                          // STR value / class name of TORCH, TENSOR, STORAGE
+    std::vector<std::pair<Ref, Ref>> items;   // TABLE
+    Ref payload;                              // TORCH: its field table (may be null)
+    // TENSOR
+    std::vector<long long> size, stride;
+    long long offset = 0;                     // 0-based
+    Ref storage;
+    // STORAGE
+    std::vector<float> data;
+};
+
+struct Reader {
+    FILE *f = nullptr;
+    std::string err;
+    std::map<int, Ref> seen;
+    bool ok = true;
+
+    bool rd(void *p, size_t n)
+    {
+        if (!ok) return false;
+        if (fread(p, 1, n, f) != n) { ok = false; err = "unexpected end of file"; return false; }
+        return true;
+    }
+    int i32() { int32_t v = 0; rd(&v, 4); return v; }
+    long long i64() { int64_t v = 0; rd(&v, 8); return v; }
+    double f64() { double v = 0; rd(&v, 8); return v; }
+    std::string str()
+    {
+        const int n = i32();
+        if (!ok || n < 0 || n > (1 << 28)) { ok = false; if (err.empty()) err = "bad string length"; return ""; }
+        std::string s((size_t)n, '\0');
+        if (n) rd(&s[0], (size_t)n);
+        return s;
+    }
+
+    static int elem_size(const std::string &cls)
+    {
+        if (cls.find("Double") != std::string::npos) return 8;
+        if (cls.find("Long") != std::string::npos) return 8;
+        if (cls.find("Half") != std::string::npos) return 2;
+        if (cls.find("Short") != std::string::npos) return 2;
+        if (cls.find("Byte") != std::string::npos || cls.find("Char") != std::string::npos) return 1;
+        return 4;   // Float, Cuda (= float), Int
+    }
+
+    Ref object(int depth = 0)
+    {
+        Ref o = std::make_shared<Obj>();
+        if (!ok) return o;
+        if (depth > 4000) { ok = false; err = "object nesting too deep"; return o; }
+        const int tag = i32();
+        switch (tag) {
+            case 0: o->kind = Obj::NIL; return o;
+            case 1: o->kind = Obj::NUM; o->num = f64(); return o;
+            case 2: o->kind = Obj::STR; o->str = str(); return o;
+            case 5: o->kind = Obj::BOOL; o->b = i32() != 0; return o;
+            case 3: case 4: case 6: case 7: case 8: break;
+            default: ok = false; err = "unknown type tag " + std::to_string(tag); return o;
+        }
+        const int idx = i32();
+        auto it = seen.find(idx);
+        if (it != seen.end()) return it->second;
+        seen[idx] = o;
+        if (tag == 3) {
+            o->kind = Obj::TABLE;
+            const int n = i32();
+            if (n < 0) { ok = false; err = "negative table size"; return o; }
+            for (int i = 0; i < n && ok; ++i) {
+                Ref k = object(depth + 1);
+                Ref v = object(depth + 1);
+                o->items.emplace_back(k, v);
+            }
+            return o;
+        }
+        if (tag == 4) {
+            std::string version = str();
+            std::string cls;
+            if (version.compare(0, 2, "V ") == 0) cls = str();
+            else cls = version;   // legacy files have no version string
+            o->str = cls;
+            const bool is_tensor = cls.size() > 6 && cls.compare(0, 6, "torch.") == 0 && cls.find("Tensor") != std::string::npos;
+            const bool is_storage = cls.size() > 6 && cls.compare(0, 6, "torch.") == 0 && cls.find("Storage") != std::string::npos;
+            if (is_tensor) {
+                o->kind = Obj::TENSOR;
+                const int nd = i32();
+                if (nd < 0 || nd > 16) { ok = false; err = "bad tensor rank"; return o; }
+                for (int i = 0; i < nd; ++i) o->size.push_back(i64());
+                for (int i = 0; i < nd; ++i) o->stride.push_back(i64());
+                o->offset = i64() - 1;
+                o->storage = object(depth + 1);
+                return o;
+            }
+            if (is_storage) {
+                o->kind = Obj::STORAGE;
+                const long long n = i64();
+                const int es = elem_size(cls);
+                if (n < 0 || n > (1ll << 33)) { ok = false; err = "bad storage size"; return o; }
+                std::vector<char> raw((size_t)n * es);
+                if (n) rd(raw.data(), raw.size());
+                o->data.resize((size_t)n);
+                for (long long i = 0; i < n && ok; ++i) {
+                    const char *p = raw.data() + (size_t)i * es;
+                    if (cls.find("Double") != std::string::npos) { double v; memcpy(&v, p, 8); o->data[i] = (float)v; }
+                    else if (cls.find("Long") != std::string::npos) { int64_t v; memcpy(&v, p, 8); o->data[i] = (float)v; }
+                    else if (cls.find("Int") != std::string::npos) { int32_t v; memcpy(&v, p, 4); o->data[i] = (float)v; }
+                    else if (es == 4) { float v; memcpy(&v, p, 4); o->data[i] = v; }
+                    else if (es == 1) o->data[i] = (float)(unsigned char)p[0];
+                    else o->data[i] = 0.f;   // half / short: not used by the shipped models
+                }
+                return o;
+            }
+            o->kind = Obj::TORCH;
+            o->payload = object(depth + 1);   // the table of fields
+            return o;
+        }
+        // functions: dumped bytecode string + upvalue table; not needed, but must be consumed
+        o->kind = Obj::FUNC;
+        (void)str();
+        (void)object(depth + 1);
+        return o;
+    }
+};
+
+// ---- helpers over the object graph ----
+Ref field(const Ref &o, const char *name)
 {
-    err = "cannot read '" + path + "': the .t7 reader is not built into this version";
-    return false;
+    if (!o) return nullptr;
+    const Ref &t = (o->kind == Obj::TORCH) ? o->payload : o;
+    if (!t || t->kind != Obj::TABLE) return nullptr;
+    for (auto &kv : t->items)
+        if (kv.first && kv.first->kind == Obj::STR && kv.first->str == name) return kv.second;
+    return nullptr;
+}
+
+std::vector<Ref> array_of(const Ref &t)   // Lua array part 1..n in order
+{
+    std::vector<Ref> out;
+    if (!t || t->kind != Obj::TABLE) return out;
+    std::map<long long, Ref> byidx;
+    for (auto &kv : t->items)
+        if (kv.first && kv.first->kind == Obj::NUM) byidx[(long long)kv.first->num] = kv.second;
+    for (long long i = 1;; ++i) {
+        auto it = byidx.find(i);
+        if (it == byidx.end()) break;
+        out.push_back(it->second);
+    }
+    return out;
+}
+
+bool class_is(const Ref &o, const char *suffix)
+{
+    if (!o || (o->kind != Obj::TORCH)) return false;
+    const size_t n = strlen(suffix);
+    return o->str.size() >= n && o->str.compare(o->str.size() - n, n, suffix) == 0;
+}
+
+bool tensor_to_vector(const Ref &t, std::vector<float> &out)
+{
+    out.clear();
+    if (!t || t->kind != Obj::TENSOR || !t->storage || t->storage->kind != Obj::STORAGE) return false;
+    long long n = 1;
+    for (long long s : t->size) n *= s;
+    if (t->size.empty()) n = 0;
+    out.resize((size_t)n);
+    const std::vector<float> &st = t->storage->data;
+    std::vector<long long> idx(t->size.size(), 0);
+    for (long long i = 0; i < n; ++i) {
+        long long off = t->offset;
+        for (size_t d = 0; d < idx.size(); ++d) off += idx[d] * t->stride[d];
+        if (off < 0 || off >= (long long)st.size()) return false;
+        out[(size_t)i] = st[(size_t)off];
+        for (int d = (int)idx.size() - 1; d >= 0; --d) {
+            if (++idx[d] < t->size[d]) break;
+            idx[d] = 0;
+        }
+    }
+    return true;
+}
+
+Ref find_gmodule(const Ref &o, std::set<const Obj *> &visited, int depth = 0)
+{
+    if (!o || depth > 64 || visited.count(o.get())) return nullptr;
+    visited.insert(o.get());
+    if (class_is(o, "nn.gModule")) return o;
+    const Ref &t = (o->kind == Obj::TORCH) ? o->payload : o;
+    if (!t || t->kind != Obj::TABLE) return nullptr;
+    // DataParallelTable keeps its replicas in `modules` (util.lua:50-58); search the fields
+    for (auto &kv : t->items) {
+        if (!kv.second) continue;
+        if (kv.second->kind == Obj::TORCH || kv.second->kind == Obj::TABLE) {
+            Ref r = find_gmodule(kv.second, visited, depth + 1);
+            if (r) return r;
+        }
+    }
+    return nullptr;
+}
+
+struct ConvW {
+    int ci = 0, co = 0, stride = 1;
+    std::vector<float> w, b;
+};
+
+bool read_conv(const Ref &m, ConvW &c, std::string &err)
+{
+    Ref ni = field(m, "nInputPlane"), no = field(m, "nOutputPlane"), dw = field(m, "dW");
+    if (!ni || !no) { err = "SpatialConvolution without nInputPlane/nOutputPlane"; return false; }
+    c.ci = (int)ni->num; c.co = (int)no->num; c.stride = dw ? (int)dw->num : 1;
+    if (!tensor_to_vector(field(m, "weight"), c.w) || !tensor_to_vector(field(m, "bias"), c.b)) {
+        err = "SpatialConvolution without readable weight/bias"; return false;
+    }
+    if ((long long)c.w.size() != (long long)c.co * c.ci * 9 || (int)c.b.size() != c.co) {
+        err = "SpatialConvolution weight is not Co x Ci x 3 x 3"; return false;
+    }
+    return true;
+}
+
+// sign summary of the nn.MulConstant nodes reachable from `node` through up-sampling / identity
+// nodes (depth-limited): bit0 = a positive constant seen, bit1 = a negative one.
+int mulconstant_signs(const Ref &node, int depth)
+{
+    if (!node || depth > 6) return 0;
+    int s = 0;
+    for (const Ref &ch : array_of(field(node, "children"))) {
+        Ref data = field(ch, "data");
+        Ref mod = data ? field(data, "module") : nullptr;
+        if (!mod) continue;
+        if (class_is(mod, "MulConstant")) {
+            Ref k = field(mod, "constant_scalar");
+            if (k && k->num > 0) s |= 1;
+            if (k && k->num < 0) s |= 2;
+        } else if (class_is(mod, "SpatialUpSamplingBilinear") || class_is(mod, "Identity")) {
+            s |= mulconstant_signs(ch, depth + 1);
+        }
+    }
+    return s;
+}
+
+}  // namespace
+
+bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow, std::string &err)
+{
+    Reader R;
+    R.f = fopen(path.c_str(), "rb");
+    if (!R.f) { err = "cannot open '" + path + "'"; return false; }
+    Ref root = R.object();
+    fclose(R.f);
+    if (!R.ok) { err = "'" + path + "' is not a readable binary .t7 file: " + R.err; return false; }
+    std::set<const Obj *> visited;
+    Ref g = find_gmodule(root, visited);   // unwraps nn.DataParallelTable, back2future.lua:114-116
+    if (!g) { err = "no nn.gModule found in '" + path + "'"; return false; }
+    std::vector<Ref> nodes = array_of(field(g, "forwardnodes"));
+    if (nodes.empty()) { err = "gModule has no forwardnodes"; return false; }
+
+    static const int kLevelOfFeatIn[8] = {0, 0, 3, 16, 32, 64, 96, 128};   // nInputPlane of convUnit l
+    std::map<int, std::vector<ConvW>> feat;                               // level -> 2 convs
+    std::map<std::pair<int, int>, std::vector<ConvW>> dec;                // (level, kind) -> 6 convs
+    std::set<const Obj *> seen_seq;
+    for (const Ref &node : nodes) {
+        Ref data = field(node, "data");
+        Ref mod = data ? field(data, "module") : nullptr;
+        if (!mod || !class_is(mod, "nn.Sequential") || seen_seq.count(mod.get())) continue;
+        seen_seq.insert(mod.get());
+        std::vector<ConvW> convs;
+        for (const Ref &sub : array_of(field(mod, "modules"))) {
+            if (!class_is(sub, "SpatialConvolution")) continue;
+            ConvW c;
+            if (!read_conv(sub, c, err)) return false;
+            convs.push_back(std::move(c));
+        }
+        if (convs.size() == 2) {
+            int level = 0;
+            for (int l = 2; l <= 7; ++l)
+                if (convs[0].ci == kLevelOfFeatIn[l] && convs[0].co == kFeatH[l]) level = l;
+            if (!level) { err = "unexpected convUnit shape"; return false; }
+            if (!feat.count(level)) feat[level] = std::move(convs);   // the three siamese clones share weights
+        } else if (convs.size() == 6) {
+            const int n = convs[0].ci;
+            int level = 0;
+            for (int l = 3; l <= 7; ++l)
+                if (n == kNDh + kFeatH[l] + 2 || (l == 7 && (n == kNDh || n == kNDh + kFeatH[7]))) level = l;
+            if (!level) { err = "unexpected decoder input width " + std::to_string(n); return false; }
+            int kind;
+            bool to_softmax = false;
+            for (const Ref &ch : array_of(field(node, "children"))) {
+                Ref d2 = field(ch, "data");
+                Ref m2 = d2 ? field(d2, "module") : nullptr;
+                if (m2 && class_is(m2, "SpatialSoftMax")) to_softmax = true;
+            }
+            if (to_softmax) kind = KIND_OCC;
+            else kind = (mulconstant_signs(node, 0) & 1) ? KIND_FLOW : KIND_PAST;
+            if (dec.count({level, kind})) { err = "two decoders with the same role at level " + std::to_string(level); return false; }
+            dec[{level, kind}] = std::move(convs);
+        }
+    }
+    past_flow = false;
+    for (auto &kv : dec)
+        if (kv.first.second == KIND_PAST) past_flow = true;
+    Ref pf = field(g, "past_flow");   // model.past_flow, pwc.lua:494
+    if (pf && pf->kind == Obj::BOOL && pf->b != past_flow) { err = "past_flow field disagrees with the graph"; return false; }
+
+    long long total = 0;
+    const std::vector<ConvDesc> lay = weight_layout(past_flow, &total);
+    flat.assign((size_t)total, 0.f);
+    for (const ConvDesc &d : lay) {
+        const ConvW *src = nullptr;
+        if (d.kind == KIND_FEAT) {
+            auto it = feat.find(d.level);
+            if (it != feat.end()) src = &it->second[(size_t)d.idx - 1];
+        } else {
+            auto it = dec.find({d.level, d.kind});
+            if (it != dec.end()) src = &it->second[(size_t)d.idx - 1];
+        }
+        if (!src) { err = "model is missing a convolution (level " + std::to_string(d.level) + ")"; return false; }
+        if (src->ci != d.ci || src->co != d.co) { err = "convolution shape mismatch at level " + std::to_string(d.level); return false; }
+        memcpy(flat.data() + d.w_off, src->w.data(), src->w.size() * sizeof(float));
+        memcpy(flat.data() + d.b_off, src->b.data(), src->b.size() * sizeof(float));
+    }
+    return true;
 }
 
 }  // namespace b2f

@@ -1,0 +1,219 @@
+"""Minimal Torch7 binary serializer + a builder of the serialized multi-frame PWC gModule
+(tests only).
+
+The reference's pretrained .t7 files are Dropbox links (README.md:49-52), none is in the tree and
+Torch7 is not installed, so the .t7 reader (csrc/b2f_t7.cpp) is exercised against files written
+here: same binary object format [3P torch7 File.lua] and the same object structure nngraph
+produces for models/pwc.lua:87-508 (gModule.forwardnodes -> nngraph.Node{data={module=...},
+children={...}}; nn.Sequential{modules={...}}; cudnn.SpatialConvolution{weight, bias,
+nInputPlane, nOutputPlane, dW, ...}; shared storages for the siamese clones; optional
+nn.DataParallelTable wrapper; torch.CudaTensor payloads).  This validates the reader against our
+understanding of the format, not against a real file (DESIGN.md says so).
+"""
+import struct
+
+import numpy as np
+
+from back2future_amd import weights as W
+
+
+class Storage(object):
+    def __init__(self, cls, arr):
+        self.cls, self.arr = cls, np.ascontiguousarray(arr)
+
+
+class Tensor(object):
+    def __init__(self, cls, storage, size, stride=None, offset=0):
+        self.cls, self.storage, self.size = cls, storage, list(size)
+        if stride is None:
+            stride, s = [], 1
+            for n in reversed(self.size):
+                stride.insert(0, s)
+                s *= n
+        self.stride, self.offset = list(stride), offset
+
+
+class TorchObj(object):
+    def __init__(self, cls, **fields):
+        self.cls, self.fields = cls, dict(fields)
+
+
+class Writer(object):
+    def __init__(self, f):
+        self.f, self.ids, self.next = f, {}, 1
+
+    def i32(self, v): self.f.write(struct.pack("<i", int(v)))
+    def i64(self, v): self.f.write(struct.pack("<q", int(v)))
+    def f64(self, v): self.f.write(struct.pack("<d", float(v)))
+    def string(self, s):
+        b = s.encode()
+        self.i32(len(b)); self.f.write(b)
+
+    def ref(self, obj):
+        """returns True if the object was written before (only its index is emitted)"""
+        k = id(obj)
+        if k in self.ids:
+            self.i32(self.ids[k]); return True
+        self.ids[k] = self.next; self.i32(self.next); self.next += 1
+        return False
+
+    def obj(self, o):
+        if o is None:
+            self.i32(0)
+        elif isinstance(o, bool):
+            self.i32(5); self.i32(1 if o else 0)
+        elif isinstance(o, (int, float, np.integer, np.floating)):
+            self.i32(1); self.f64(o)
+        elif isinstance(o, str):
+            self.i32(2); self.string(o)
+        elif isinstance(o, (list, tuple)):
+            self.i32(3)
+            if self.ref(o): return
+            self.i32(len(o))
+            for i, v in enumerate(o):
+                self.obj(i + 1); self.obj(v)
+        elif isinstance(o, dict):
+            self.i32(3)
+            if self.ref(o): return
+            self.i32(len(o))
+            for k, v in o.items():
+                self.obj(k); self.obj(v)
+        elif isinstance(o, Storage):
+            self.i32(4)
+            if self.ref(o): return
+            self.string("V 1"); self.string(o.cls)
+            self.i64(o.arr.size); self.f.write(o.arr.tobytes())
+        elif isinstance(o, Tensor):
+            self.i32(4)
+            if self.ref(o): return
+            self.string("V 1"); self.string(o.cls)
+            self.i32(len(o.size))
+            for s in o.size: self.i64(s)
+            for s in o.stride: self.i64(s)
+            self.i64(o.offset + 1)
+            self.obj(o.storage)
+        elif isinstance(o, TorchObj):
+            self.i32(4)
+            if self.ref(o): return
+            self.string("V 1"); self.string(o.cls)
+            self.obj(o.fields)
+        else:
+            raise TypeError(type(o))
+
+
+def _conv(cls_prefix, tcls, scls, w, b, stride, share=None):
+    """cudnn/nn.SpatialConvolution with weight/bias (+ grads, like a checkpoint after clearState)."""
+    co, ci = w.shape[0], w.shape[1]
+    if share is None:
+        ws, bs = Storage(scls, w.astype(np.float32)), Storage(scls, b.astype(np.float32))
+        gws, gbs = Storage(scls, np.zeros(w.size, np.float32)), Storage(scls, np.zeros(b.size, np.float32))
+    else:
+        ws, bs, gws, gbs = share
+    m = TorchObj(cls_prefix + ".SpatialConvolution",
+                 nInputPlane=ci, nOutputPlane=co, kW=3, kH=3, dW=stride, dH=stride, padW=1, padH=1,
+                 weight=Tensor(tcls, ws, (co, ci, 3, 3)), bias=Tensor(tcls, bs, (co,)),
+                 gradWeight=Tensor(tcls, gws, (co, ci, 3, 3)), gradBias=Tensor(tcls, gbs, (co,)),
+                 train=False)
+    return m, (ws, bs, gws, gbs)
+
+
+def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False):
+    """The object tree torch.save(model) would produce for createModelMulti(opt) with the shipped
+    options (pwc.lua:87-508).  Only what the reader may look at is faithful: node/module classes,
+    children links, Sequential contents, tensor sharing, MulConstant constants, model fields."""
+    v = W.views(np.asarray(flat, np.float32), past_flow)
+    tcls = "torch.CudaTensor" if cuda else "torch.FloatTensor"
+    scls = "torch.CudaStorage" if cuda else "torch.FloatStorage"
+    cp = "cudnn" if cudnn else "nn"
+    nodes = []
+
+    def node(module, *parents):
+        n = TorchObj("nngraph.Node", data={"module": module, "mapindex": [p.fields["data"] for p in parents]},
+                     children=[], visited=False, id=len(nodes) + 1)
+        nodes.append(n)
+        for p in parents:
+            p.fields["children"].append(n)
+        return n
+
+    def seq(mods):
+        return TorchObj("nn.Sequential", modules=list(mods), train=False)
+
+    lrelu = lambda: TorchObj("nn.LeakyReLU", negval=0.2, inplace=True)
+
+    inp = node(TorchObj("nn.Identity"))
+    Is = {f: node(TorchObj("nn.Narrow", dimension=2, index=(f - 1) * 3 + 1, length=3), inp) for f in (1, 2, 3)}
+    ds = {}
+    for f in (1, 3):
+        ds[f] = {1: Is[f]}
+        for l in range(2, 6):
+            ds[f][l] = node(TorchObj(cp + ".SpatialAveragePooling", kW=2, kH=2, dW=2, dH=2), ds[f][l - 1])
+    # siamese feature towers: frames 2 and 3 are clones sharing the storages of frame 1 (pwc.lua:187-195)
+    cs, shares = {}, {}
+    for f in (1, 2, 3):
+        cs[f] = {1: Is[f]}
+        for l in range(2, 8):
+            c1, s1 = _conv(cp, tcls, scls, v["feat%d.conv1.w" % l], v["feat%d.conv1.b" % l], 2, shares.get((l, 1)))
+            c2, s2 = _conv(cp, tcls, scls, v["feat%d.conv2.w" % l], v["feat%d.conv2.b" % l], 1, shares.get((l, 2)))
+            shares[(l, 1)], shares[(l, 2)] = s1, s2
+            cs[f][l] = node(seq([c1, lrelu(), c2, lrelu()]), cs[f][l - 1])
+
+    def decoder(l, kind):
+        mods = []
+        for i in range(1, 7):
+            c, _ = _conv(cp, tcls, scls, v["l%d.%s.conv%d.w" % (l, kind, i)], v["l%d.%s.conv%d.b" % (l, kind, i)], 1)
+            mods.append(c)
+            if i < 6:
+                mods.append(lrelu())
+        return seq(mods)
+
+    def warp(I, F):   # warpingUnit, pwc.lua:68-73
+        a = node(TorchObj("nn.Transpose", permutations=[[2, 3], [3, 4]]), I)
+        b = node(TorchObj("nn.Transpose", permutations=[[2, 3], [3, 4]]), F)
+        s = node(TorchObj("nn.BilinearSamplerBHWD"), a, b)
+        return node(TorchObj("nn.Transpose", permutations=[[3, 4], [2, 3]]), s)
+
+    up = lambda p: node(TorchObj("nn.SpatialUpSamplingBilinear", scale_factor=2.0), p)
+    nn2 = lambda p: node(TorchObj("nn.SpatialUpSamplingNearest", scale_factor=2.0), p)
+    mulc = lambda p, k: node(TorchObj("nn.MulConstant", constant_scalar=float(k), inplace=False), p)
+    ws = {1: {}, 3: {}}
+    ufs, ubfs, outs = {}, {}, {}
+    for l in range(7, 2, -1):
+        src = cs if l == 7 else ws
+        cvf = node(TorchObj("nn.CostVolMulti", win=9, fwd=True, verbose=False), cs[2][l], src[3][l])
+        cvb = node(TorchObj("nn.CostVolMulti", win=9, fwd=False, verbose=False), cs[2][l], src[1][l])
+        cv = node(TorchObj("nn.JoinTable", dimension=2), cvf, cvb)
+        oin = [cv, cs[2][l]] + ([ufs[l + 1]] if l != 7 else [])
+        occ = node(TorchObj(cp + ".SpatialSoftMax"), node(decoder(l, "occ"), node(TorchObj("nn.JoinTable", dimension=2), *oin)))
+        skip_occ = nn2(nn2(occ))
+        if l == 7:
+            fs = node(decoder(l, "flow"), cv)
+            bfs = node(decoder(l, "past"), cv) if past_flow else None
+        else:
+            fs = node(decoder(l, "flow"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ufs[l + 1]))
+            bfs = node(decoder(l, "past"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ubfs[l + 1])) if past_flow else None
+        ufs[l] = up(fs)
+        skip_u = up(ufs[l])
+        if past_flow:
+            ubfs[l] = up(bfs)
+            skip_ub = up(ubfs[l])
+        iws = {}
+        for f in (1, 3):
+            if l > 3:
+                ws[f][l - 1] = warp(cs[f][l - 1], mulc(ufs[l], 20.0 * (f - 2) / 2 ** (l - 2)))
+            tmp = skip_ub if (past_flow and f < 2) else skip_u
+            iws[f] = warp(ds[f][l - 2], mulc(tmp, 20.0 * (f - 2) / 2 ** (l - 3)))
+        outs[l] = [skip_u] + ([skip_ub] if past_flow else []) + [skip_occ, iws[1], iws[3]]
+    out_nodes = [n for l in range(3, 8) for n in outs[l]]
+    outnode = node(TorchObj("nn.Identity"), *out_nodes)
+    modules = [n.fields["data"]["module"] for n in nodes]
+    g = TorchObj("nn.gModule", forwardnodes=nodes, modules=modules, outnode=outnode, innode=inp,
+                 nInputs=1, verbose=False, train=False, past_flow=bool(past_flow),
+                 flow_scale=[20.0 / 2 ** (l - 3) for l in range(7, 2, -1)])
+    if dpt:
+        g = TorchObj("nn.DataParallelTable", modules=[g], gpuAssignments=[1], dimension=1, train=False)
+    return g
+
+
+def save(path, flat, past_flow, **kw):
+    with open(path, "wb") as f:
+        Writer(f).obj(build_model(flat, past_flow, **kw))

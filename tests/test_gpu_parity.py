@@ -216,8 +216,8 @@ def test_graph_replay_matches_eager(soft):
 
 def test_errors_are_loud(hard):
     from back2future_amd._lib import B2FError
-    with pytest.raises(B2FError):
-        back2future.Model("Ours-Hard")            # models/RoamingImages_H.t7 is not in the tree
+    with pytest.raises(B2FError, match="cannot open"):
+        back2future.Model("Ours-Hard")            # models/RoamingImages_H.t7 is not in the tree (cwd = repo root)
     with pytest.raises(B2FError):
         back2future.Model("no-such-model")
     with pytest.raises(B2FError):
@@ -239,3 +239,32 @@ def test_full_forward_table_vs_oracle(hard, soft, which):
     for i, (a, b) in enumerate(zip(outs, exp)):
         assert a.shape == b.shape
         assert np.abs(a - b).max() <= 1e-3, (i, float(np.abs(a - b).max()))
+
+
+def test_init_from_t7_file_and_reference_names(tmp_path, hard):
+    """back2future.init('Ours-Hard') resolves models/RoamingImages_H.t7 relative to the current
+    directory (back2future.lua:100-113); the .t7 is read by the library itself."""
+    import os
+    from tests import t7_writer
+    flat = W.random_init(5, False, 2.0)
+    mdir = tmp_path / "models"
+    mdir.mkdir()
+    t7_writer.save(str(mdir / "RoamingImages_H.t7"), flat, False, dpt=True)
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        m = back2future.Model("Ours-Hard")
+    finally:
+        os.chdir(cwd)
+    assert not m.past_flow
+    np.testing.assert_array_equal(m.get_weights(), flat)
+    r = _rng(3)
+    im = _triplet(r, 64, 128)
+    f1, fo1, bo1 = m.computeFlow(*im)
+    f2, fo2, bo2 = hard.computeFlow(*im)            # same weights through "random:hard:5:2.0"
+    np.testing.assert_array_equal(f1, f2)
+    np.testing.assert_array_equal(fo1, fo2)
+    m.close()
+    m2 = back2future.Model(str(mdir / "RoamingImages_H.t7"))
+    np.testing.assert_array_equal(m2.get_weights(), flat)
+    m2.close()
