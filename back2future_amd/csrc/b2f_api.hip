@@ -72,6 +72,7 @@ struct b2f_ctx {
     float *w_dev = nullptr;     // flat canonical weights
     float *wpk_dev = nullptr;   // packed kernel-side copies
     size_t wpk_floats = 0;
+    size_t first_w_off = 0, first_b_off = 0;   // [27][16] weights + bias of the first pyramid conv (conv_first_kernel)
     // workspace arena
     float *arena = nullptr;
     size_t arena_floats = 0;
@@ -156,6 +157,8 @@ int prof_collect(b2f_ctx *c)
 //   decoder layer 1                 : segment 0 = cs[ref][l] (C_l channels),
 //                                     segment 1 = cost-volume record (slot order in b2f_internal.h)
 // while the Torch order of pwc.lua:308,334 is {cv 162, cs[ref][l] C_l, flow 2}.
+int find_conv(const b2f_ctx *c, int kind, int level, int idx);
+
 int pack_all(b2f_ctx *c, const float *flat)
 {
     const size_t n = c->lay.size();
@@ -202,7 +205,17 @@ int pack_all(b2f_ctx *c, const float *flat)
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
     }
+    c->first_w_off = total; total += 27 * 16;
+    c->first_b_off = total; total += 16;
     std::vector<float> host(total, 0.f);
+    {
+        const int id = find_conv(c, KIND_FEAT, 2, 1);   // Torch 16 x 3 x 3 x 3 -> [tap (c,ky,kx)][cout]
+        const ConvDesc &d = c->lay[(size_t)id];
+        for (int o = 0; o < 16; ++o) {
+            for (int t = 0; t < 27; ++t) host[c->first_w_off + (size_t)t * 16 + o] = flat[d.w_off + (size_t)o * 27 + t];
+            host[c->first_b_off + o] = flat[d.b_off + o];
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         const ConvDesc &d = c->lay[i];
         const PackedConv &p = c->packed[i];
@@ -246,7 +259,7 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     for (int l = 1; l <= 7; ++l) { p.h[l] = H >> (l - 1); p.w[l] = W >> (l - 1); }
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; };
-    p.img = take((size_t)3 * B * H * W * kImgC);
+    p.img = full ? take((size_t)3 * B * H * W * kImgC) : 0;   // packed frames: only the full table needs them
     p.tmp = take((size_t)3 * B * p.h[2] * p.w[2] * kFeat[2]);
     for (int l = 2; l <= 7; ++l) p.cs[l] = take((size_t)3 * B * p.h[l] * p.w[l] * kFeat[l]);
     for (int l = 3; l <= 6; ++l) p.U[l] = take((size_t)B * p.h[l] * p.w[l] * 2);
@@ -365,16 +378,23 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
     float *A = c->arena;
     const int B = P.B;
     const bool full = P.full, past = c->past_flow && full;
-    {
+    const int unit = in_kind == B2F_IN_UNIT;
+    if (full) {   // the packed frames are only needed for the image pyramid / image warps of the full table
         Scope sc(c, s, "pack_input", cap);
-        HIPCHK(launch_pack_input((const float *)dev_in, in_kind == B2F_IN_UNIT, B, P.H, P.W, A + P.img, s));
+        HIPCHK(launch_pack_input((const float *)dev_in, unit, B, P.H, P.W, A + P.img, s));
     }
     // siamese feature pyramid, the three frames batched (shared weights, pwc.lua:169-211)
     for (int l = 2; l <= 7; ++l) {
         const int hi = P.h[l - 1], wi = P.w[l - 1], ho = P.h[l], wo = P.w[l];
         const int Ci = (l == 2) ? kImgC : kFeat[l - 1], Co = kFeat[l];
-        const ConvSeg in1 = cp8_seg((l == 2) ? A + P.img : A + P.cs[l - 1], Ci, (size_t)hi * wi);
-        CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp));
+        if (l == 2) {
+            Scope sc(c, s, "conv_first", cap);
+            HIPCHK(launch_conv_first((const float *)dev_in, unit, B, P.H, P.W, c->wpk_dev + c->first_w_off,
+                                     c->wpk_dev + c->first_b_off, A + P.tmp, s));
+        } else {
+            const ConvSeg in1 = cp8_seg(A + P.cs[l - 1], Ci, (size_t)hi * wi);
+            CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp));
+        }
         const ConvSeg in2 = cp8_seg(A + P.tmp, Co, (size_t)ho * wo);
         CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l]));
     }
@@ -458,7 +478,8 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
     if (!full && O.est3 && !c->past_flow) {
         // Hard: est[3] = iws[1][3] = warp(I1, skip_ufs[3] * 20*(1-2)/2^0)  (pwc.lua:422-446,459-489)
         Scope sc(c, s, "warp_image", cap);
-        HIPCHK(launch_warp_image_planar(A + P.img, O.flow ? O.flow : A + P.flow_planar, -20.0f, B, P.H, P.W, O.est3, s));
+        HIPCHK(launch_warp_input_planar((const float *)dev_in, unit, 0, O.flow ? O.flow : A + P.flow_planar, -20.0f, B, P.H, P.W,
+                                        O.est3, s));
     }
     return 0;
 }

@@ -208,6 +208,122 @@ hipError_t launch_warp_image_planar(const float *img8, const float *flow_planar,
     return hipGetLastError();
 }
 
+
+// ---- first layer of the siamese pyramid straight from the API tensor: torch.cat + ColorNormalize
+// (back2future.lua:48-49, transforms.lua:33-45) + nn.Narrow (pwc.lua:139-145) + convUnit's first
+// nn.SpatialConvolution(3,16,3,3,2,2,1,1) + LeakyReLU(0.2) (pwc.lua:58-61) in ONE pass over the
+// planar B x 9 x H x W input: no packed NHWC copy of the frames is ever written (that copy was
+// 96 B/pixel of HBM writes).  HBM-bound: 36 B read + 48 B written per input pixel.  Block = 256
+// threads = 8 x 32 output pixels of one (frame, batch) image; the 17 x 65 x 3 input patch is
+// normalized once into LDS; weights [tap 27][cout 16] come in as scalar (SGPR) operands.
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int normalize, int B, int H, int W,
+                                                         const float *wt /*27 x 16*/, const float *bias /*16*/,
+                                                         float *out /*[3][B][2][H/2*W/2][8]*/)
+{
+    constexpr int TH = 8, TW = 32, PH = 2 * TH + 1, PW = 2 * TW + 1;
+    __shared__ float patch[3][PH][PW + 1];
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;          // f * B + b
+    const int f = img / B, b = img - f * B;
+    const int ox0 = tx_i * TW, oy0 = ty_i * TH;
+    const int ix0 = 2 * ox0 - 1, iy0 = 2 * oy0 - 1;
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    const size_t hw = (size_t)H * W;
+    const float *src = in + ((size_t)b * 9 + (size_t)f * 3) * hw;
+    for (int i = threadIdx.x; i < 3 * PH * PW; i += 256) {
+        const int c = i / (PH * PW), r = i - c * (PH * PW);
+        const int py = r / PW, px = r - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        float v = 0.f;                                   // zero padding of the NORMALIZED image
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = src[(size_t)c * hw + (size_t)gy * W + gx];
+            if (normalize) v = __fdiv_rn(v + (-mean[c]), stdv[c]);   // add(-mean) then div(std)
+        }
+        patch[c][py][px] = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = bias[o];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = patch[c][2 * ty + ky][2 * tx + kx];
+                const float *w = wt + ((c * 3 + ky) * 3 + kx) * 16;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, w[o], acc[o]);
+            }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= Ho || ox >= Wo) return;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = acc[o] > 0.f ? acc[o] : 0.2f * acc[o];
+    const size_t hwo = (size_t)Ho * Wo;
+    float *op = out + (size_t)img * hwo * 16 + ((size_t)oy * Wo + ox) * 8;
+    *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(op + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    *reinterpret_cast<float4 *>(op + hwo * 8) = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    *reinterpret_cast<float4 *>(op + hwo * 8 + 4) = make_float4(acc[12], acc[13], acc[14], acc[15]);
+}
+
+hipError_t launch_conv_first(const float *in, int normalize, int B, int H, int W, const float *wt, const float *bias,
+                             float *out, hipStream_t s)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles = ((Wo + 31) / 32) * ((Ho + 7) / 8);
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(tiles * 3 * B)), dim3(256), 0, s, in, normalize, B, H, W, wt, bias, out);
+    return hipGetLastError();
+}
+
+// ---- iws[1][3] for Hard models straight from the planar API tensor: frame `frame` of in
+// (B x 9 x H x W), normalized on the fly, warped by k * planar flow -> planar B x 3 x H x W ----
+__global__ void warp_input_planar_kernel(const float *in, int normalize, int frame, const float *flow, float k, int B,
+                                         int H, int W, float *out)
+{
+    const size_t hw = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * hw) return;
+    const size_t b = i / hw, p = i - b * hw;
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const float u = flow[(b * 2) * hw + p] * k, v = flow[(b * 2 + 1) * hw + p] * k;
+    int xl, yt;
+    float wx, wy;
+    top_left_g(u + (float)x, W, xl, wx);
+    top_left_g(v + (float)y, H, yt, wy);
+    const int dx = (xl + 1 <= W - 1) ? 1 : 0, dy = (yt + 1 <= H - 1) ? W : 0;   // weight is 0 when folded
+    const float w00 = wx * wy, w01 = (1.f - wx) * wy, w10 = wx * (1.f - wy), w11 = (1.f - wx) * (1.f - wy);
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *src = in + (b * 9 + (size_t)frame * 3 + c) * hw + (size_t)yt * W + xl;
+        float tl = src[0], tr = src[dx], bl = src[dy], br = src[dy + dx];
+        if (normalize) {
+            tl = __fdiv_rn(tl + (-mean[c]), stdv[c]); tr = __fdiv_rn(tr + (-mean[c]), stdv[c]);
+            bl = __fdiv_rn(bl + (-mean[c]), stdv[c]); br = __fdiv_rn(br + (-mean[c]), stdv[c]);
+        }
+        out[(b * 3 + c) * hw + p] = w00 * tl + w01 * tr + w10 * bl + w11 * br;
+    }
+}
+
+hipError_t launch_warp_input_planar(const float *in, int normalize, int frame, const float *flow_planar, float k, int B,
+                                    int H, int W, float *out, hipStream_t s)
+{
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp_input_planar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, normalize, frame,
+                       flow_planar, k, B, H, W, out);
+    return hipGetLastError();
+}
+
 // ---- nn.SpatialAveragePooling(2,2,2,2) (pwc.lua:155) on NHWC, float4 over channels ----
 __global__ void avgpool2_kernel(const float *in, int nimg, int H, int W, int C, float *out)
 {

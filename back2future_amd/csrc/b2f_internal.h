@@ -85,6 +85,13 @@ hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int
 // planar B x 9 x H x W -> 3 frame-major NHWC8 images ([3][B][H][W][8]), optional normalize
 hipError_t launch_pack_input(const float *in, int normalize, int B, int H, int W, float *img,
                              hipStream_t s);
+// first pyramid layer (ColorNormalize + Narrow + conv 3->16 s2 + LeakyReLU) from the planar input;
+// wt = [27 taps (c,ky,kx)][16 cout], out = chunk-planar [3][B][2][H/2*W/2][8]
+hipError_t launch_conv_first(const float *in, int normalize, int B, int H, int W, const float *wt,
+                             const float *bias, float *out, hipStream_t s);
+// warp frame `frame` of the planar input (normalized on the fly) by k * planar flow
+hipError_t launch_warp_input_planar(const float *in, int normalize, int frame, const float *flow_planar,
+                                    float k, int B, int H, int W, float *out, hipStream_t s);
 // nn.BilinearSamplerBHWD forward (CUDA semantics), grid scaled by k
 hipError_t launch_warp_nhwc(const float *img, long img_stride, int pix_stride, int C, int ih,
                             int iw, const float *grid, float k, int B, int gh, int gw,

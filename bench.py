@@ -181,14 +181,14 @@ def main():
             "outputs_finite": finite,
         }
         if prof:
-            conv_ms = sum(ms for k, (ms, n) in prof.items() if k.startswith("conv3x3")) / args.steps
-            conv_n = sum(n for k, (ms, n) in prof.items() if k.startswith("conv3x3")) / args.steps
+            conv_ms = sum(ms for k, (ms, n) in prof.items() if k.startswith("conv")) / args.steps
+            conv_n = sum(n for k, (ms, n) in prof.items() if k.startswith("conv")) / args.steps
             corr_ms, corr_n = prof.get("warp_costvol", (0.0, 0))
             corr_ms /= args.steps
             corr_n /= args.steps
             flops = conv_flops_per_px() * px
             a = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-            out["roofline"] = {"kernel": "conv3x3_mfma (all %d launches of a step)" % conv_n, "bound": "mfma",
+            out["roofline"] = {"kernel": "conv3x3_mfma + conv_first (all %d conv launches of a step)" % conv_n, "bound": "mfma",
                                "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
                                "traffic": None, "ms_per_step": conv_ms,
                                "algorithmic_flop_per_step": flops}
