@@ -28,6 +28,14 @@
 // reference pixel, software-pipelined one 9-displacement column ahead.  The bwd thread runs the
 // same code on the mirrored window (bwd channel c uses offset +q = fwd offset of channel 80 - c).
 // Blocks are remapped so that each XCD (private L2) works on one contiguous band of tiles.
+//
+// Measured dead ends (round 1, MI355X, kept out of the tree): 3-pixel register
+// blocking (fewer LDS reads: slower, LDS was never the limiter), 3 threads per pixel-direction
+// (more loads in flight: +6 %), software-pipelining the gather across chunks (no gain), producer /
+// consumer wave specialization (2x slower: the gather is VALU-issue-bound, not latency-bound),
+// v_pk_fma_f32 on (fwd, bwd) pairs with interleaved maps (slower: packed FMA issues at half rate).
+// What did pay: chunk-planar inputs/outputs (whole-line gathers and stores), XCD remap, a cheap
+// gather (per-pixel state in LDS, one thread fetches both float4 of a chunk, fma blend).
 #include "b2f_internal.h"
 
 #include <cstdlib>
@@ -248,186 +256,6 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Wave-specialized variant (the default): same tile, records and maths as warp_costvol_kernel,
-// but a block has 6 waves: waves 0..3 are CONSUMERS (one pixel x direction per thread, 81
-// accumulators, correlate chunk c out of LDS buffer c&1) and waves 4..5 are PRODUCERS (no
-// accumulators: gather + blend the warped halo of chunk c+1 into buffer (c+1)&1, 12 items per
-// thread, up to 24 loads in flight).  One barrier per chunk.  In the single-role kernel above the
-// three resident blocks of a CU run their gather / FMA phases in lock-step, so the phase times add
-// up; here memory latency and FMA issue overlap by construction.
-namespace pc {
-constexpr int HPP = 24;                    // unpadded halo pitch: two buffers fit 2 blocks / CU
-constexpr int NBUF = 2 * 2 * HH * HPP;     // float4 per buffer: [map][k4][16 x 24]
-}  // namespace pc
-
-template <bool POW2>
-__global__ __launch_bounds__(384, 3) void warp_costvol_pc_kernel(const CorrLaunch p)
-{
-    using namespace pc;
-    __shared__ __attribute__((aligned(16))) float4 nb[2 * NBUF];         // 48 KB
-    __shared__ float4 samp_w[2][NHALO];                                  // 12 KB
-    __shared__ SampIdx samp_i[2][NHALO];                                 // 6 KB
-
-    const int tid = threadIdx.x;
-    const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
-    int bid = (p.ablate & 8) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    const int tx_i = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty_i = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int x0 = tx_i * TW, y0 = ty_i * TH;
-
-    const float *ref = p.ref + (size_t)b * p.img_stride;
-    const float *nbr[2] = {p.nbr_fut + (size_t)b * p.img_stride, p.nbr_past + (size_t)b * p.img_stride};
-
-    for (int i = tid; i < 2 * NHALO; i += 384) {
-        const int map = i / NHALO, hp = i - map * NHALO;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int y = y0 - R + hy, x = x0 - R + hx;
-        float4 wgt = make_float4(0.f, 0.f, 0.f, 0.f);
-        SampIdx si;
-        si.idx = 0; si.flags = 0;
-        if (y >= 0 && y < p.h && x >= 0 && x < p.w) {
-            float u = 0.f, v = 0.f;
-            if (p.flow) {
-                const float2 f = *reinterpret_cast<const float2 *>(p.flow + ((size_t)(b * p.h + y) * p.w + x) * 2);
-                const float k = map == 0 ? p.k : -p.k;   // nn.MulConstant(20*(f-ref)/2^(l-2)), pwc.lua:404
-                u = f.x * k; v = f.y * k;
-            }
-            int xl, yt;
-            float wx, wy;
-            top_left(u + (float)x, p.w, xl, wx);
-            top_left(v + (float)y, p.h, yt, wy);
-            si.idx = yt * p.w + xl;
-            si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
-            wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
-        }
-        samp_w[map][hp] = wgt;
-        samp_i[map][hp] = si;
-    }
-    __syncthreads();
-
-    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;   // wave-uniform role
-    const int nchunk = p.C >> 3;
-
-    // ---- producer: gather + blend one 8-channel chunk of both halos into buffer `buf` ----
-    auto gather = [&](int ch, int buf) {
-        const int ptid = tid - 256;
-        const size_t coff = (size_t)ch * p.chunk_stride;
-        float4 *dstb = nb + buf * NBUF;
-#pragma unroll 6   // 24 gathers in flight per thread
-        for (int i = ptid; i < 2 * 2 * NHALO; i += 128) {
-            const int k4 = i & 1;
-            const int rest = i >> 1;
-            const int map = rest / NHALO, hp = rest - map * NHALO;
-            const float4 wg = samp_w[map][hp];
-            const SampIdx si = samp_i[map][hp];
-            const float *src = nbr[map] + coff + (size_t)si.idx * p.pix_stride + 4 * k4;
-            const int dx = si.flags & 1, dy = (si.flags & 2) ? p.w : 0;
-            const float4 tl = *reinterpret_cast<const float4 *>(src);
-            const float4 tr = *reinterpret_cast<const float4 *>(src + dx * p.pix_stride);
-            const float4 bl = *reinterpret_cast<const float4 *>(src + (size_t)dy * p.pix_stride);
-            const float4 br = *reinterpret_cast<const float4 *>(src + (size_t)(dy + dx) * p.pix_stride);
-            float4 v;
-            v.x = wg.x * tl.x + wg.y * tr.x + wg.z * bl.x + wg.w * br.x;
-            v.y = wg.x * tl.y + wg.y * tr.y + wg.z * bl.y + wg.w * br.y;
-            v.z = wg.x * tl.z + wg.y * tr.z + wg.z * bl.z + wg.w * br.z;
-            v.w = wg.x * tl.w + wg.y * tr.w + wg.z * bl.w + wg.w * br.w;
-            dstb[(map * 2 + k4) * (HH * HPP) + hp] = v;   // hp = hy * 24 + hx: the unpadded pitch
-        }
-    };
-
-    // Two separate loops, one per role, with the same number of barriers (1 + nchunk): the 81
-    // accumulators are never live in a producer wave, and the producers' in-flight gathers are
-    // never live in a consumer wave.
-    if (producer) {
-        gather(0, 0);
-        __syncthreads();
-        for (int ch = 0; ch < nchunk; ++ch) {
-            if (ch + 1 < nchunk) gather(ch + 1, (ch + 1) & 1);
-            __syncthreads();
-        }
-        return;
-    }
-
-    float acc[81];
-#pragma unroll
-    for (int i = 0; i < 81; ++i) acc[i] = 0.f;
-    const int pl = tid & 127, dir = (tid >> 7) & 1;
-    const int ly = pl >> 4, lx = pl & 15;
-    const int py = y0 + ly, px = x0 + lx;
-    const bool pvalid = py < p.h && px < p.w;
-    const float *refp = ref + (size_t)(pvalid ? (py * p.w + px) : 0) * p.pix_stride;
-    const int my_off = dir * 2 * (HH * HPP) + (ly + R) * HPP + (lx + R);
-
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const size_t coff = (size_t)ch * p.chunk_stride;
-        const float4 r01[2] = {*reinterpret_cast<const float4 *>(refp + coff), *reinterpret_cast<const float4 *>(refp + coff + 4)};
-        const float4 *myn = nb + (ch & 1) * NBUF + my_off;
-        float4 va[9], vb[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) va[j] = myn[-(j - 4) * HPP + 4];
-#pragma unroll
-        for (int st = 0; st < 18; ++st) {
-            const int k4 = st / 9, g = st - 9 * k4;
-            const float4 r = r01[k4];
-            float4 *cur = (st & 1) ? vb : va, *nxt = (st & 1) ? va : vb;
-            if (st + 1 < 18) {
-                const int k4n = (st + 1) / 9, gn = (st + 1) - 9 * k4n;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) nxt[j] = myn[k4n * (HH * HPP) - (j - 4) * HPP - (gn - 4)];
-            }
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                float a = acc[g * 9 + j];
-                a = fmaf(r.x, cur[j].x, a);
-                a = fmaf(r.y, cur[j].y, a);
-                a = fmaf(r.z, cur[j].z, a);
-                a = fmaf(r.w, cur[j].w, a);
-                acc[g * 9 + j] = a;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-
-    if (!pvalid) return;
-    if ((p.ablate & 4) && acc[0] != 12345.678f) return;
-    const float cf = (float)p.C, inv = 1.f / cf;
-#pragma unroll
-    for (int c = 0; c < 81; ++c) acc[c] = POW2 ? acc[c] * inv : acc[c] / cf;   // output:div(N), CostVolMulti.lua:100
-    const size_t pix = (size_t)py * p.w + px;
-    float *o = p.out + (size_t)b * p.out_img_stride + pix * p.out_pix_stride;
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        float4 lo, hi;
-        if (dir == 0) {
-            lo = make_float4(acc[8 * j], acc[8 * j + 1], acc[8 * j + 2], acc[8 * j + 3]);
-            hi = make_float4(acc[8 * j + 4], acc[8 * j + 5], acc[8 * j + 6], acc[8 * j + 7]);
-        } else {
-            lo = make_float4(acc[80 - 8 * j], acc[79 - 8 * j], acc[78 - 8 * j], acc[77 - 8 * j]);
-            hi = make_float4(acc[76 - 8 * j], acc[75 - 8 * j], acc[74 - 8 * j], acc[73 - 8 * j]);
-        }
-        float *oc = o + (size_t)(dir * 10 + j) * p.out_chunk_stride;
-        *reinterpret_cast<float4 *>(oc) = lo;
-        *reinterpret_cast<float4 *>(oc + 4) = hi;
-    }
-    float *ol = o + (size_t)20 * p.out_chunk_stride;
-    if (dir == 0) {
-        ol[0] = acc[80];
-    } else {
-        const size_t fp = ((size_t)b * p.h * p.w + pix) * 2;
-        float2 f = make_float2(0.f, 0.f), fb = make_float2(0.f, 0.f);
-        if (p.flow) f = *reinterpret_cast<const float2 *>(p.flow + fp);
-        if (p.flow_b) fb = *reinterpret_cast<const float2 *>(p.flow_b + fp);
-        ol[1] = acc[0];
-        ol[2] = f.x; ol[3] = f.y;
-        *reinterpret_cast<float4 *>(ol + 4) = make_float4(fb.x, fb.y, 0.f, 0.f);
-    }
-}
-
 hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
 {
     if (p_in.C % 8 != 0 || p_in.pix_stride % 4 != 0 || p_in.chunk_stride % 4 != 0 || p_in.out_pix_stride % 4 != 0 ||
@@ -439,12 +267,6 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * p.B));
-    static const int variant = getenv("B2F_CORR_VARIANT") ? atoi(getenv("B2F_CORR_VARIANT")) : 5;
-    if (variant == 5) {
-        if (pow2) hipLaunchKernelGGL(warp_costvol_pc_kernel<true>, grid, dim3(384), 0, s, p);
-        else hipLaunchKernelGGL(warp_costvol_pc_kernel<false>, grid, dim3(384), 0, s, p);
-        return hipGetLastError();
-    }
     if (pow2) hipLaunchKernelGGL(warp_costvol_kernel<true>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(warp_costvol_kernel<false>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
