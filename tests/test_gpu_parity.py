@@ -268,3 +268,20 @@ def test_init_from_t7_file_and_reference_names(tmp_path, hard):
     m2 = back2future.Model(str(mdir / "RoamingImages_H.t7"))
     np.testing.assert_array_equal(m2.get_weights(), flat)
     m2.close()
+
+
+def test_reference_sample_triplet(soft):
+    """BASELINE.json configs[0]: samples/frame_0009..0011.png (375 x 1242 -> net 320 x 1216, the
+    host image.scale path at its real size).  The pretrained .t7 is not available, so the weights
+    are the seeded random Soft set; bar 1e-3 on the rescaled flow."""
+    import os
+    from back2future_amd import flow_io
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "samples")
+    ims = [flow_io.load_image(os.path.join(d, "frame_%04d.png" % i)) for i in (9, 10, 11)]
+    assert ims[0].shape == (3, 375, 1242)
+    flow, fo, bo = soft.computeFlow(*ims)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(ims[0], ims[1], ims[2], W.random_init(5, True, 2.0), True, want_net=True)
+    assert fnet.shape == (2, 320, 1216)
+    assert np.abs(flow - eflow).max() <= 1e-3
+    near = O.image_scale_simple((np.abs(onet - 0.6666) < 1e-3).astype(np.uint8), 375, 1242).astype(bool)
+    assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
