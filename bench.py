@@ -88,6 +88,22 @@ def cpu_baseline(H, W, seed):
                       "with OpenMP on all host cores, %.2f s" % (h, w, dt)}
 
 
+def pmc_traffic(B, H, W):
+    """HBM bytes per step from the committed PMC passes (profiles/*_traffic.json, produced by
+    tools/collect_traffic.sh + tools/traffic_summary.py on this same command); only valid for
+    the default workload they were collected on."""
+    import glob
+    if (B, H, W) != (16, 1024, 1920):
+        return {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        d = json.load(f)
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,18 +202,21 @@ def main():
             corr_ms, corr_n = prof.get("warp_costvol", (0.0, 0))
             corr_ms /= args.steps
             corr_n /= args.steps
+            tr = pmc_traffic(B, H, W)
             flops = conv_flops_per_px() * px
             a = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
             out["roofline"] = {"kernel": "conv3x3_mfma + conv_first (all %d conv launches of a step)" % conv_n, "bound": "mfma",
                                "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
-                               "traffic": None, "ms_per_step": conv_ms,
+                               "traffic": tr.get("conv", {}).get("traffic_bytes"), "traffic_unit": "HBM bytes per step (PMC)",
+                               "traffic_source": tr.get("file"), "ms_per_step": conv_ms,
                                "algorithmic_flop_per_step": flops}
             cb = corr_bytes_per_px() * px
             g = cb / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
             out["roofline_corrwarp"] = {"kernel": "warp_costvol (%d launches of a step)" % corr_n, "bound": "hbm",
                                         "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0,
-                                        "traffic": None, "ms_per_step": corr_ms,
-                                        "algorithmic_bytes_per_step": cb}
+                                        "traffic": tr.get("warp_costvol", {}).get("traffic_bytes"),
+                                        "traffic_unit": "HBM bytes per step (PMC)", "traffic_source": tr.get("file"),
+                                        "ms_per_step": corr_ms, "algorithmic_bytes_per_step": cb}
             out["kernel_ms_per_step"] = {k: ms / args.steps for k, (ms, n) in sorted(prof.items())}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, 2)
