@@ -42,6 +42,7 @@ struct PackedConv {
     int nseg = 1;
     int chunks[2] = {0, 0};
     int cout = 0, nt = 1, nblk = 1;
+    bool wino = false;             // Winograd F(2x2,3x3) kernel (stride-1 layers)
     size_t w_off = 0, b_off = 0;   // float offsets into wpk_dev
 };
 
@@ -159,6 +160,13 @@ int prof_collect(b2f_ctx *c)
 // while the Torch order of pwc.lua:308,334 is {cv 162, cs[ref][l] C_l, flow 2}.
 int find_conv(const b2f_ctx *c, int kind, int level, int idx);
 
+// B2F_WINO=0 falls back to the direct implicit-GEMM kernel everywhere (A/B runs, parity tests)
+bool use_wino()
+{
+    static const bool on = !(getenv("B2F_WINO") && atoi(getenv("B2F_WINO")) == 0);
+    return on;
+}
+
 int pack_all(b2f_ctx *c, const float *flat)
 {
     const size_t n = c->lay.size();
@@ -169,7 +177,12 @@ int pack_all(b2f_ctx *c, const float *flat)
         const ConvDesc &d = c->lay[i];
         PackedConv &p = c->packed[i];
         p.cout = d.co;
-        conv_choose_tiles(d.co, &p.nt, &p.nblk);
+        // stride-1 layers with >= 16 outputs run on the Winograd kernel (the first conv of a convUnit
+        // has stride 2, the last decoder layer has 2 outputs: direct kernel)
+        const bool stride1 = !(d.kind == KIND_FEAT && d.idx == 1);
+        p.wino = use_wino() && stride1 && d.co >= 16;
+        if (p.wino) wino_choose_tiles(d.co, &p.nt, &p.nblk);
+        else conv_choose_tiles(d.co, &p.nt, &p.nblk);
         std::vector<int> &m = maps[i];
         if (d.kind != KIND_FEAT && d.idx == 1) {
             const int Cl = kFeat[d.level];
@@ -201,7 +214,7 @@ int pack_all(b2f_ctx *c, const float *flat)
         }
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
         p.w_off = total;
-        total += conv_wpk_floats(chunks, p.nt, p.nblk);
+        total += p.wino ? wino_wpk_floats(chunks, p.nt, p.nblk) : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
     }
@@ -220,8 +233,12 @@ int pack_all(b2f_ctx *c, const float *flat)
         const ConvDesc &d = c->lay[i];
         const PackedConv &p = c->packed[i];
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
-        conv_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
-                          host.data() + p.w_off, host.data() + p.b_off);
+        if (p.wino)
+            wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
+                              host.data() + p.w_off, host.data() + p.b_off);
+        else
+            conv_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
+                              host.data() + p.w_off, host.data() + p.b_off);
     }
     if (c->wpk_floats != total) {
         if (c->wpk_dev) HIPCHK(hipFree(c->wpk_dev));
@@ -334,9 +351,10 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.nimg = nimg;
     L.leaky = leaky;
     char name[32];
-    snprintf(name, sizeof name, "conv3x3_s%d_nt%d", stride, p.nt);
+    snprintf(name, sizeof name, p.wino ? "conv3x3_wino_nt%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.nt);
     Scope sc(c, s, name, cap);
-    HIPCHK(launch_conv3x3(L, s));
+    if (p.wino) HIPCHK(launch_conv3x3_wino(L, s));
+    else HIPCHK(launch_conv3x3(L, s));
     return 0;
 }
 
@@ -1013,9 +1031,12 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     const int chunks = (Ci + kCK - 1) / kCK, Cp = chunks * kCK;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int nt, nblk;
-    conv_choose_tiles(Co, &nt, &nblk);
-    std::vector<float> wpk(conv_wpk_floats(chunks, nt, nblk)), bpk((size_t)nblk * nt * 32);
-    conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
+    const bool wino = use_wino() && stride == 1 && Co >= 16;
+    if (wino) wino_choose_tiles(Co, &nt, &nblk);
+    else conv_choose_tiles(Co, &nt, &nblk);
+    std::vector<float> wpk(wino ? wino_wpk_floats(chunks, nt, nblk) : conv_wpk_floats(chunks, nt, nblk)), bpk((size_t)nblk * nt * 32);
+    if (wino) wino_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
+    else conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     DevBuf dpl, dx, dw, db, dy, dyp;
     const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
     CHK(dpl.alloc(nx)); CHK(dx.alloc(nxp)); CHK(dw.alloc(wpk.size())); CHK(db.alloc(bpk.size())); CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
@@ -1031,7 +1052,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.wpk = dw.p; L.bias = db.p; L.out = dy.p;
     L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_chunk_stride = 8; L.out_pix_stride = Co; L.cout = Co;
     L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
-    HIPCHK(launch_conv3x3(L, c->stream));
+    if (wino) HIPCHK(launch_conv3x3_wino(L, c->stream));
+    else HIPCHK(launch_conv3x3(L, c->stream));
     HIPCHK(launch_nhwc_to_planar(dy.p, Co, Co, B, Ho, Wo, dyp.p, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(y, dyp.p, ny * sizeof(float), hipMemcpyDeviceToHost));

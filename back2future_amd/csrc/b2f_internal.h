@@ -60,6 +60,14 @@ void conv_choose_tiles(int cout, int *nt, int *nblk);
 void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
                        int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
 
+// ---- Winograd F(2x2,3x3) variant for stride-1 layers (b2f_wino.hip); same ConvLaunch, weights
+// packed by wino_pack_weights ([nblk][chunk][xi 16][k4 2][NT*32][4]), nt in {1, 2}
+hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s);
+void wino_choose_tiles(int cout, int *nt, int *nblk);
+size_t wino_wpk_floats(int cin_chunks, int nt, int nblk);
+void wino_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
+                       int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
+
 // ---- fused warp + cost volume -----------------------------------------------------
 struct CorrLaunch {
     const float *ref, *nbr_fut, *nbr_past;  // C channels each

@@ -1,0 +1,324 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 MFMA for gfx950 (MI355X): the stride-1
+// nn.SpatialConvolution(Ci,Co,3,3,1,1,1,1) [+ LeakyReLU(0.2)] layers of /root/reference/models/
+// pwc.lua:62 (second conv of every convUnit) and :78-82 (decoder layers), i.e. ~85 % of the
+// FLOPs of computeFlow.  Same maths as b2f_conv.hip (cross-correlation, zero padding, bias first,
+// LeakyReLU fused, chunk-planar in/out, up to two input K-segments) with 2.25x fewer MFMA MACs:
+//
+//   Y(2x2) = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        d = 4x4 input tile, g = 3x3 filter
+//
+// The 16 element-wise products become 16 independent GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci]
+// U_xi[ci][co]  (xi = 4a + b), run on v_mfma_f32_32x32x2_f32 (exact fp32).  U = G g G^T is
+// pre-computed on the host (wino_pack_weights); only additions happen on the device besides the
+// MFMAs, so the result differs from the direct kernel by fp32 re-association only (~1e-6 rel.).
+//
+// Block = 512 threads (8 waves) -> 16 x 16 output pixels = 64 Winograd tiles, NT*32 output
+// channels; wave w owns xi = 2w, 2w+1 for both 32-tile M halves and all NT N tiles
+// (2 x 2 x NT accumulator tiles = 64*NT VGPRs).  K is walked in chunks of 8 input channels:
+//   raw  [2 buf][2 k4][18 x 18] float4            input patch with halo
+//   V    [2 buf][16 xi][2 k4][64 tiles] float4   transformed input  (A operand)
+//   U    [2 buf][16 xi][2 k4][NT*32 co] float4   transformed weights (B operand, linear copy)
+// One barrier per chunk: while the MFMAs of chunk c run, the same waves transform chunk c+1
+// (raw -> V: b128 LDS traffic only, 8 vector adds per thread, hidden under the 64-cycle MFMAs) and the
+// global loads of raw(c+2) and U(c+1) are in flight.  After the last chunk the accumulators go
+// through LDS ([xi][tile][co]) so that one thread holds all 16 xi of a (tile, co) pair, applies
+// A^T . A, bias, LeakyReLU and stores the 2x2 outputs.
+#include "b2f_internal.h"
+
+#include <vector>
+
+namespace b2f {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace wino {
+constexpr int PW = 18;                 // patch width/height: 16 outputs + 2 halo
+constexpr int RAW_P = 328;             // float4 per k4 plane (18*18 = 324 pixels, padded)
+constexpr int RAW_F4 = 2 * RAW_P;      // float4 per raw buffer: [k4][pixel]
+constexpr int V_F4 = 16 * 2 * 64;      // float4 per V buffer
+constexpr int A_F4 = 2 * PW * PW;      // float4 items of one patch chunk (pixel, k4)
+}  // namespace wino
+
+template <int NT>
+__global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
+{
+    using namespace wino;
+    constexpr int NB = NT * 32;
+    constexpr int U_F4 = 16 * 2 * NB;
+    constexpr int U_PER_THREAD = U_F4 / 512;         // 4 (NT=2) or 2 (NT=1)
+    constexpr int A_PER_THREAD = (A_F4 + 511) / 512; // 2
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
+    f32x4 *Ub = Vb + 2 * V_F4;                                    // [2][U_F4]
+    f32x4 *Rb = Ub + 2 * U_F4;                                    // [2][RAW_F4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, half = lane >> 5;
+
+    const int tiles_x = (p.Wo + 15) / 16, tiles_y = (p.Ho + 15) / 16;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int nb = blockIdx.y;
+    const int ox0 = tx_i * 16, oy0 = ty_i * 16;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
+
+    // ---- staging coordinates of the raw patch (fixed over chunks) ----
+    int a_goff[A_PER_THREAD], a_pix[A_PER_THREAD];
+    bool a_ok[A_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+        const int idx = tid + i * 512;
+        const int pix = idx >> 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        a_ok[i] = (idx < A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_goff[i] = a_ok[i] ? (gy * p.W + gx) : 0;
+        a_pix[i] = (idx < A_F4) ? pix : -1;
+    }
+    const int a_h = tid & 1;
+
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * U_F4;
+
+    f32x4 ra[A_PER_THREAD], ru[U_PER_THREAD];
+#define WINO_LOAD_RAW(c_)                                                                           \
+    do {                                                                                            \
+        const int c__ = (c_);                                                                       \
+        const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
+        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
+        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
+        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;                            \
+        const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
+        const float *ib = base + (size_t)img * istr + (size_t)cc * cstr + a_h * 4;                  \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
+            ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
+    } while (0)
+#define WINO_LOAD_U(c_)                                                                             \
+    do {                                                                                            \
+        const f32x4 *wb = wsrc + (size_t)(c_) * U_F4;                                               \
+        _Pragma("unroll") for (int i = 0; i < U_PER_THREAD; ++i) ru[i] = wb[tid + i * 512];         \
+    } while (0)
+#define WINO_WRITE_RAW(buf_)                                                                        \
+    do {                                                                                            \
+        f32x4 *r = Rb + (buf_) * RAW_F4 + a_h * RAW_P;                                              \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i) {                                  \
+            const f32x4 v = a_ok[i] ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f};                            \
+            if ((i + 1) * 512 <= A_F4) r[a_pix[i]] = v;                                             \
+            else if (a_pix[i] >= 0) r[a_pix[i]] = v;                                                \
+        }                                                                                           \
+    } while (0)
+#define WINO_WRITE_U(buf_)                                                                          \
+    do {                                                                                            \
+        f32x4 *u = Ub + (buf_) * U_F4;                                                              \
+        _Pragma("unroll") for (int i = 0; i < U_PER_THREAD; ++i) u[tid + i * 512] = ru[i];          \
+    } while (0)
+
+    // input transform of one chunk, V_xi = (B^T d B)[a][b] with xi = 4a + b, on float4 = 4 channels:
+    // thread = (tile t = tid & 63, row a = (tid >> 6) & 3, k4 = tid >> 8); row a of B^T d needs two
+    // rows of the 4x4 input tile, so a thread reads 8 float4 and writes the 4 float4 V[4a + b].
+    // a and k4 are wave-uniform; all LDS traffic is b128 and the V writes are conflict-free.
+    const int t_tile = tid & 63, t_a = (tid >> 6) & 3, t_k4 = tid >> 8;
+    const int t_r0 = (t_a == 0) ? 0 : 1;                 // rows of d combined by B^T row a:
+    const int t_r1 = (t_a == 3) ? 3 : 2;                 //   a=0: d0-d2, a=1: d1+d2, a=2: d2-d1, a=3: d1-d3
+    const float t_s0 = (t_a == 2) ? -1.f : 1.f;
+    const float t_s1 = (t_a == 1 || t_a == 2) ? 1.f : -1.f;
+    const int t_src = t_k4 * RAW_P + (2 * (t_tile >> 3)) * PW + 2 * (t_tile & 7);
+    const int t_dst = (t_a * 4 * 2 + t_k4) * 64 + t_tile;   // float4 index of V[xi = 4a][k4][t]; xi+1 -> +128
+#define WINO_TRANSFORM(rbuf_, vbuf_)                                                                \
+    do {                                                                                            \
+        const f32x4 *r = Rb + (rbuf_) * RAW_F4 + t_src;                                             \
+        f32x4 *v = Vb + (vbuf_) * V_F4 + t_dst;                                                     \
+        f32x4 w[4];                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) w[j] = t_s0 * r[t_r0 * PW + j] + t_s1 * r[t_r1 * PW + j]; \
+        v[0] = w[0] - w[2]; v[128] = w[1] + w[2]; v[256] = w[2] - w[1]; v[384] = w[1] - w[3];       \
+    } while (0)
+
+    f32x16 acc[2][2][NT];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][mt][nt][r] = 0.f;
+
+    // ---- prologue ----
+    WINO_LOAD_RAW(0);
+    WINO_LOAD_U(0);
+    WINO_WRITE_RAW(0);
+    WINO_WRITE_U(0);
+    if (nchunks > 1) {
+        WINO_LOAD_RAW(1);
+        WINO_WRITE_RAW(1);
+    }
+    __syncthreads();
+    WINO_TRANSFORM(0, 0);
+    __syncthreads();
+
+    const int a_off = (2 * wave * 2 + half) * 64 + m;        // xi = 2*wave (+1: +128), k4 = half
+    const int b_off = (2 * wave * 2 + half) * NB + m;
+    for (int c = 0; c < nchunks; ++c) {
+        // branch-free body (one basic block: the scheduler can put the transform's LDS / VALU work and the
+        // staging under the MFMAs): past the end the loads re-fetch the last chunk and the transform /
+        // writes go to buffers nobody reads any more.
+        WINO_LOAD_RAW(min(c + 2, nchunks - 1));
+        WINO_LOAD_U(min(c + 1, nchunks - 1));
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
+        const f32x4 *Uc = Ub + (c & 1) * U_F4 + b_off;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            f32x4 a[2], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = Vc[x * 128 + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = Uc[x * 2 * NB + nt * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[x][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[x][mt][nt], 0, 0, 0);
+        }
+        WINO_TRANSFORM((c + 1) & 1, (c + 1) & 1);
+        WINO_WRITE_RAW(c & 1);
+        WINO_WRITE_U((c + 1) & 1);
+        __syncthreads();
+    }
+#undef WINO_LOAD_RAW
+#undef WINO_LOAD_U
+#undef WINO_WRITE_RAW
+#undef WINO_WRITE_U
+#undef WINO_TRANSFORM
+
+    // ---- output: accumulators -> LDS [xi][tile][co] -> A^T M A + bias (+ LeakyReLU) -> store ----
+    float *X = reinterpret_cast<float *>(smem);   // 16 * 64 * 32 floats = 128 KB (V and U are dead)
+    float *ob = p.out + (size_t)img * p.out_img_stride;
+    const int o_n = tid & 31, o_tq = tid >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    X[((2 * wave + x) * 64 + t) * 32 + m] = acc[x][mt][nt][r];
+                }
+        __syncthreads();
+        const int co = nb * NB + nt * 32 + o_n;
+        const float bias = p.bias[co];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int t = o_tq + 16 * jj;
+            float mm[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) mm[a][bq] = X[((a * 4 + bq) * 64 + t) * 32 + o_n];
+            float s[2][4];
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                s[0][bq] = mm[0][bq] + mm[1][bq] + mm[2][bq];
+                s[1][bq] = mm[1][bq] - mm[2][bq] - mm[3][bq];
+            }
+            const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float y[2];
+                y[0] = bias + (s[i][0] + s[i][1] + s[i][2]);
+                y[1] = bias + (s[i][1] - s[i][2] - s[i][3]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = y[j];
+                    if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+                    if (co < p.cout && oy + i < p.Ho && ox + j < p.Wo)
+                        ob[(size_t)(co >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co & 7)] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NT>
+static hipError_t launch_wino_t(const ConvLaunch &p, hipStream_t s)
+{
+    using namespace wino;
+    const size_t lds = sizeof(f32x4) * (2 * V_F4 + 2 * 16 * 2 * NT * 32 + 2 * RAW_F4);
+    const size_t lds_need = lds > 131072 ? lds : 131072;   // the output exchange needs 128 KB
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    dim3 grid((unsigned)(tiles * p.nimg), (unsigned)p.nblk);
+    hipLaunchKernelGGL((conv3x3_wino<NT>), grid, dim3(512), lds_need, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s)
+{
+    if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return hipErrorInvalidValue;
+    if (p.nt == 1) return launch_wino_t<1>(p, s);
+    if (p.nt == 2) return launch_wino_t<2>(p, s);
+    return hipErrorInvalidValue;
+}
+
+void wino_choose_tiles(int cout, int *nt, int *nblk)
+{
+    if (cout <= 32) { *nt = 1; *nblk = 1; }
+    else { *nt = 2; *nblk = (cout + 63) / 64; }
+}
+
+size_t wino_wpk_floats(int cin_chunks, int nt, int nblk)
+{
+    return (size_t)nblk * cin_chunks * 16 * 2 * nt * 32 * 4;
+}
+
+// U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]) in double, rounded once to fp32;
+// packed [nblk][chunk][xi 16][k4 2][NT*32 co][4 ci].
+void wino_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks,
+                       int nt, int nblk, float *wpk, float *bpk)
+{
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int NB = nt * 32;
+    std::vector<double> U((size_t)Co * Ci * 16);
+    for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float *g = w + ((size_t)co * Ci + ci) * 9;
+            double t[4][3];
+            for (int a = 0; a < 4; ++a)
+                for (int v = 0; v < 3; ++v) t[a][v] = G[a][0] * g[0 * 3 + v] + G[a][1] * g[1 * 3 + v] + G[a][2] * g[2 * 3 + v];
+            for (int a = 0; a < 4; ++a)
+                for (int bq = 0; bq < 4; ++bq)
+                    U[((size_t)co * Ci + ci) * 16 + a * 4 + bq] = t[a][0] * G[bq][0] + t[a][1] * G[bq][1] + t[a][2] * G[bq][2];
+        }
+    for (int nbk = 0; nbk < nblk; ++nbk)
+        for (int c = 0; c < cin_chunks; ++c)
+            for (int xi = 0; xi < 16; ++xi)
+                for (int h = 0; h < 2; ++h)
+                    for (int nn = 0; nn < NB; ++nn)
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = nbk * NB + nn;
+                            const int k = c * kCK + h * 4 + j;
+                            const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
+                            float v = 0.f;
+                            if (co < Co && ci >= 0) v = (float)U[((size_t)co * Ci + ci) * 16 + xi];
+                            wpk[((((((size_t)nbk * cin_chunks + c) * 16 + xi) * 2 + h) * NB + nn) * 4) + j] = v;
+                        }
+    for (int i = 0; i < nblk * NB; ++i) bpk[i] = i < Co ? b[i] : 0.f;
+}
+
+}  // namespace b2f

@@ -65,7 +65,8 @@ def test_conv3x3_transpose_detecting(hard):
         wt = np.zeros((33, 8, 3, 3), np.float32)
         wt[co, ci, ky, kx] = 1
         got = ops.conv3x3(hard, x, wt, np.zeros(33, np.float32), 1, False)
-        np.testing.assert_array_equal(got, O.conv3x3(x, wt, np.zeros(33, np.float32), 1, False))
+        # stride-1 layers run on the Winograd kernel: same values up to fp32 re-association of the transforms
+        np.testing.assert_allclose(got, O.conv3x3(x, wt, np.zeros(33, np.float32), 1, False), rtol=0, atol=4e-6)
 
 
 @pytest.mark.parametrize("C,h,w", [(32, 24, 40), (192, 4, 7), (96, 9, 17), (8, 1, 2), (64, 16, 16)])
