@@ -16,7 +16,7 @@
 // (2 x 2 x NT accumulator tiles = 64*NT VGPRs).  K is walked in chunks of 8 input channels:
 //   raw  [2 buf][2 k4][18 x 18] float4            input patch with halo
 //   V    [2 buf][16 xi][2 k4][64 tiles] float4   transformed input  (A operand)
-//   U    [2 buf][16 xi][2 k4][NT*32 co] float4   transformed weights (B operand, linear copy)
+//   U    [16 xi][2 k4][NT*32 co] float4 per chunk: B operand, read straight from global (never in LDS)
 // One barrier per chunk: while the MFMAs of chunk c run, the same waves transform chunk c+1
 // (raw -> V: b128 LDS traffic only, 8 vector adds per thread, hidden under the 64-cycle MFMAs) and the
 // global loads of raw(c+2) and U(c+1) are in flight.  After the last chunk the accumulators go
@@ -24,6 +24,7 @@
 // A^T . A, bias, LeakyReLU and stores the 2x2 outputs.
 #include "b2f_internal.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace b2f {
@@ -45,13 +46,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
     using namespace wino;
     constexpr int NB = NT * 32;
     constexpr int U_F4 = 16 * 2 * NB;
-    constexpr int U_PER_THREAD = U_F4 / 512;         // 4 (NT=2) or 2 (NT=1)
     constexpr int A_PER_THREAD = (A_F4 + 511) / 512; // 2
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
-    f32x4 *Ub = Vb + 2 * V_F4;                                    // [2][U_F4]
-    f32x4 *Rb = Ub + 2 * U_F4;                                    // [2][RAW_F4]
+    f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
     const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * U_F4;
 
-    f32x4 ra[A_PER_THREAD], ru[U_PER_THREAD];
+    f32x4 ra[A_PER_THREAD];
 #define WINO_LOAD_RAW(c_)                                                                           \
     do {                                                                                            \
         const int c__ = (c_);                                                                       \
@@ -99,10 +98,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
         _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
             ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
     } while (0)
-#define WINO_LOAD_U(c_)                                                                             \
+#define WINO_LOAD_U(dst_, c_)                                                                       \
     do {                                                                                            \
-        const f32x4 *wb = wsrc + (size_t)(c_) * U_F4;                                               \
-        _Pragma("unroll") for (int i = 0; i < U_PER_THREAD; ++i) ru[i] = wb[tid + i * 512];         \
+        const f32x4 *wb = wsrc + (size_t)(c_) * U_F4 + b_off;                                       \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                               \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst_[x * NT + nt] = wb[x * 2 * NB + nt * 32]; \
     } while (0)
 #define WINO_WRITE_RAW(buf_)                                                                        \
     do {                                                                                            \
@@ -112,11 +112,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
             if ((i + 1) * 512 <= A_F4) r[a_pix[i]] = v;                                             \
             else if (a_pix[i] >= 0) r[a_pix[i]] = v;                                                \
         }                                                                                           \
-    } while (0)
-#define WINO_WRITE_U(buf_)                                                                          \
-    do {                                                                                            \
-        f32x4 *u = Ub + (buf_) * U_F4;                                                              \
-        _Pragma("unroll") for (int i = 0; i < U_PER_THREAD; ++i) u[tid + i * 512] = ru[i];          \
     } while (0)
 
     // input transform of one chunk, V_xi = (B^T d B)[a][b] with xi = 4a + b, on float4 = 4 channels:
@@ -149,59 +144,90 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][mt][nt][r] = 0.f;
 
+    // B operands (transformed weights) never touch LDS: wave w only ever needs rows xi = 2w, 2w+1 of
+    // the chunk's U slab, so each lane loads its own float4 (k4 = half, co = nt*32 + m) straight from
+    // the packed global layout (512 contiguous bytes per half-wave), one chunk ahead.
+    const int a_off = (2 * wave * 2 + half) * 64 + m;        // xi = 2*wave (+1: +128), k4 = half
+    const int b_off = (2 * wave * 2 + half) * NB + m;
+    f32x4 bcur[2 * NT], bnxt[2 * NT];
+
     // ---- prologue ----
     WINO_LOAD_RAW(0);
-    WINO_LOAD_U(0);
+    WINO_LOAD_U(bcur, 0);
     WINO_WRITE_RAW(0);
-    WINO_WRITE_U(0);
-    if (nchunks > 1) {
-        WINO_LOAD_RAW(1);
-        WINO_WRITE_RAW(1);
-    }
+    WINO_LOAD_RAW(min(1, nchunks - 1));
+    WINO_WRITE_RAW(1);
     __syncthreads();
     WINO_TRANSFORM(0, 0);
     __syncthreads();
 
-    const int a_off = (2 * wave * 2 + half) * 64 + m;        // xi = 2*wave (+1: +128), k4 = half
-    const int b_off = (2 * wave * 2 + half) * NB + m;
     for (int c = 0; c < nchunks; ++c) {
-        // branch-free body (one basic block: the scheduler can put the transform's LDS / VALU work and the
-        // staging under the MFMAs): past the end the loads re-fetch the last chunk and the transform /
-        // writes go to buffers nobody reads any more.
-        WINO_LOAD_RAW(min(c + 2, nchunks - 1));
-        WINO_LOAD_U(min(c + 1, nchunks - 1));
+        // Branch-free body, hand-ordered with scheduling barriers so that every latency sits under
+        // MFMAs of the same SIMD (its own or the other resident wave's):
+        //   (1) issue the global loads of raw(c+2) / B(c+1) and ALL LDS reads of this iteration
+        //       (A operands of both xi, the 8 raw float4 of the transform of chunk c+1);
+        //   (2) 8*NT MFMAs of xi = 2w        -- the reads land meanwhile;
+        //   (3) the transform's vector adds and its 4 V writes (VALU/LDS under the MFMA tail);
+        //   (4) 8*NT MFMAs of xi = 2w+1;
+        //   (5) raw(c+2) -> LDS, B registers roll over, barrier.
+        // Past the last chunk the loads re-fetch the last chunk and the writes go to dead buffers.
+        if (!(p.ablate & 2)) WINO_LOAD_RAW(min(c + 2, nchunks - 1));
+        if (!(p.ablate & 4)) WINO_LOAD_U(bnxt, min(c + 1, nchunks - 1));
         const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
-        const f32x4 *Uc = Ub + (c & 1) * U_F4 + b_off;
+        f32x4 a0[2], a1[2], tr0[4], tr1[4];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            f32x4 a[2], b[NT];
+        for (int mt = 0; mt < 2; ++mt) { a0[mt] = Vc[mt * 32]; a1[mt] = Vc[128 + mt * 32]; }
+        {
+            const f32x4 *r = Rb + ((c + 1) & 1) * RAW_F4 + t_src;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = Vc[x * 128 + mt * 32];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = Uc[x * 2 * NB + nt * 32];
+            for (int j = 0; j < 4; ++j) { tr0[j] = r[t_r0 * PW + j]; tr1[j] = r[t_r1 * PW + j]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 8)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[x][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[x][mt][nt], 0, 0, 0);
+                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][j], bcur[nt][j], acc[0][mt][nt], 0, 0, 0);
         }
-        WINO_TRANSFORM((c + 1) & 1, (c + 1) & 1);
-        WINO_WRITE_RAW(c & 1);
-        WINO_WRITE_U((c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 1)) {
+            f32x4 *v = Vb + ((c + 1) & 1) * V_F4 + t_dst;
+            f32x4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = t_s0 * tr0[j] + t_s1 * tr1[j];
+            v[0] = w[0] - w[2]; v[128] = w[1] + w[2]; v[256] = w[2] - w[1]; v[384] = w[1] - w[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 8)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][j], bcur[NT + nt][j], acc[1][mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.ablate & 2)) WINO_WRITE_RAW(c & 1);
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) bcur[i] = bnxt[i];
         __syncthreads();
     }
 #undef WINO_LOAD_RAW
 #undef WINO_LOAD_U
 #undef WINO_WRITE_RAW
-#undef WINO_WRITE_U
 #undef WINO_TRANSFORM
 
     // ---- output: accumulators -> LDS [xi][tile][co] -> A^T M A + bias (+ LeakyReLU) -> store ----
     float *X = reinterpret_cast<float *>(smem);   // 16 * 64 * 32 floats = 128 KB (V and U are dead)
     float *ob = p.out + (size_t)img * p.out_img_stride;
-    const int o_n = tid & 31, o_tq = tid >> 5;
+    // one (tile, 4 consecutive couts) item per thread and N tile: 16 ds_read_b128, vector adds,
+    // four 16-byte stores (the 2x2 output pixels)
+    const int o_t = tid >> 3, o_cq = tid & 7;
+    const bool vec_ok = ((p.out_pix_stride | (int)p.out_chunk_stride) & 3) == 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -214,34 +240,43 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
                     X[((2 * wave + x) * 64 + t) * 32 + m] = acc[x][mt][nt][r];
                 }
         __syncthreads();
-        const int co = nb * NB + nt * 32 + o_n;
-        const float bias = p.bias[co];
+        const int co0 = nb * NB + nt * 32 + 4 * o_cq;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+        f32x4 mm[4][4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int t = o_tq + 16 * jj;
-            float mm[4][4];
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int bq = 0; bq < 4; ++bq)
+                mm[a][bq] = *reinterpret_cast<const f32x4 *>(X + ((a * 4 + bq) * 64 + o_t) * 32 + 4 * o_cq);
+        f32x4 sr[2][4];
 #pragma unroll
-                for (int bq = 0; bq < 4; ++bq) mm[a][bq] = X[((a * 4 + bq) * 64 + t) * 32 + o_n];
-            float s[2][4];
+        for (int bq = 0; bq < 4; ++bq) {
+            sr[0][bq] = mm[0][bq] + mm[1][bq] + mm[2][bq];
+            sr[1][bq] = mm[1][bq] - mm[2][bq] - mm[3][bq];
+        }
+        const int oy = oy0 + 2 * (o_t >> 3), ox = ox0 + 2 * (o_t & 7);
 #pragma unroll
-            for (int bq = 0; bq < 4; ++bq) {
-                s[0][bq] = mm[0][bq] + mm[1][bq] + mm[2][bq];
-                s[1][bq] = mm[1][bq] - mm[2][bq] - mm[3][bq];
-            }
-            const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+        for (int i = 0; i < 2; ++i) {
+            f32x4 y[2];
+            y[0] = bias + (sr[i][0] + sr[i][1] + sr[i][2]);
+            y[1] = bias + (sr[i][1] - sr[i][2] - sr[i][3]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float y[2];
-                y[0] = bias + (s[i][0] + s[i][1] + s[i][2]);
-                y[1] = bias + (s[i][1] - s[i][2] - s[i][3]);
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = y[j];
+                if (p.leaky) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v = y[j];
-                    if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-                    if (co < p.cout && oy + i < p.Ho && ox + j < p.Wo)
-                        ob[(size_t)(co >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co & 7)] = v;
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (oy + i < p.Ho && ox + j < p.Wo && co0 < p.cout) {
+                    float *dst = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co0 & 7);
+                    if (vec_ok && co0 + 3 < p.cout) {
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co0 + e < p.cout)
+                                ob[(size_t)((co0 + e) >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + ((co0 + e) & 7)] = v[e];
+                    }
                 }
             }
         }
@@ -253,7 +288,7 @@ template <int NT>
 static hipError_t launch_wino_t(const ConvLaunch &p, hipStream_t s)
 {
     using namespace wino;
-    const size_t lds = sizeof(f32x4) * (2 * V_F4 + 2 * 16 * 2 * NT * 32 + 2 * RAW_F4);
+    const size_t lds = sizeof(f32x4) * (2 * V_F4 + 2 * RAW_F4);
     const size_t lds_need = lds > 131072 ? lds : 131072;   // the output exchange needs 128 KB
     static bool attr_done = false;
     if (!attr_done) {
@@ -268,8 +303,11 @@ static hipError_t launch_wino_t(const ConvLaunch &p, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s)
+hipError_t launch_conv3x3_wino(const ConvLaunch &p_in, hipStream_t s)
 {
+    static const int ablate = getenv("B2F_WINO_ABLATE") ? atoi(getenv("B2F_WINO_ABLATE")) : 0;
+    ConvLaunch p = p_in;
+    p.ablate = ablate;
     if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return hipErrorInvalidValue;
     if (p.nt == 1) return launch_wino_t<1>(p, s);
     if (p.nt == 2) return launch_wino_t<2>(p, s);
