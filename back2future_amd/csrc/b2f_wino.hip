@@ -150,13 +150,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
     const int a_off = (2 * wave * 2 + half) * 64 + m;        // xi = 2*wave (+1: +128), k4 = half
     const int b_off = (2 * wave * 2 + half) * NB + m;
     f32x4 bcur[2 * NT], bnxt[2 * NT];
+    const int ntv = min(NT, (p.cout - nb * NB + 31) / 32);   // N tiles of this block that hold real channels
 
     // ---- prologue ----
-    WINO_LOAD_RAW(0);
-    WINO_LOAD_U(bcur, 0);
-    WINO_WRITE_RAW(0);
-    WINO_LOAD_RAW(min(1, nchunks - 1));
-    WINO_WRITE_RAW(1);
+    {   // raw(0) and raw(1) in flight together (one memory round trip instead of two)
+        f32x4 rb1[A_PER_THREAD];
+        WINO_LOAD_RAW(min(1, nchunks - 1));
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i) rb1[i] = ra[i];
+        WINO_LOAD_RAW(0);
+        WINO_LOAD_U(bcur, 0);
+        WINO_WRITE_RAW(0);
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i) ra[i] = rb1[i];
+        WINO_WRITE_RAW(1);
+    }
     __syncthreads();
     WINO_TRANSFORM(0, 0);
     __syncthreads();
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][j], bcur[nt][j], acc[0][mt][nt], 0, 0, 0);
+                        if (nt < ntv) acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][j], bcur[nt][j], acc[0][mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(p.ablate & 1)) {
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][j], bcur[NT + nt][j], acc[1][mt][nt], 0, 0, 0);
+                        if (nt < ntv) acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][j], bcur[NT + nt][j], acc[1][mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(p.ablate & 2)) WINO_WRITE_RAW(c & 1);
