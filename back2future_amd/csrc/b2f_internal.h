@@ -50,6 +50,7 @@ struct ConvLaunch {
     int H, W, Ho, Wo, stride;
     int nimg;
     int leaky;
+    int nb0;            // first n-block of this launch (Winograd kernel: a layer may be split over two launches)
     int ablate;         // profiling only (B2F_WINO_ABLATE): 1 no transform, 2 no raw staging, 4 no B loads, 8 no MFMAs
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);

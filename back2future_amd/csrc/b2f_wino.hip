@@ -292,6 +292,288 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second-generation kernel: same maths and packed weights, smaller blocks so that TWO independent
+// blocks share a CU.  In the 512-thread kernel above every non-MFMA phase (prologue, the part of
+// staging/transform that does not hide, the LDS output exchange) stalls the whole CU because the
+// only resident block is in the same phase on all SIMDs; with two resident blocks that drift apart
+// those phases of one block run under the MFMAs of the other.
+//
+// Block = 256 threads (4 waves) -> 8 x 16 output pixels = 32 Winograd tiles (exactly one 32-row
+// MFMA M tile), NT*32 output channels; wave w owns row a = w of the transformed 4x4 tile
+// (xi = 4w .. 4w+3, all NT N tiles: 4*NT accumulators = 64*NT VGPRs).  Per 8-channel chunk and
+// wave: 4 A operands from LDS, 4*NT B operands straight from global in two halves (xi pair 0/1 is
+// fetched while pair 2/3 multiplies and vice versa: 2 x 2*NT float4 of registers), 16*NT MFMAs.
+//   raw  [2 buf][2 k4][10 x 18] float4,   V [2 buf][16 xi][2 k4][32 tiles] float4  (44.5 KB)
+// Output: the first half of A^T M A (along b) happens in registers because a wave holds a whole
+// row a; LDS only carries T[a][j][tile][co] (8 instead of 16 planes, 72 KB for NT = 2).
+namespace wino2 {
+constexpr int TH = 8, TW = 16;
+constexpr int PH = TH + 2, PW = TW + 2;
+constexpr int RAW_P = 184;             // float4 per k4 plane (10*18 = 180 pixels, padded)
+constexpr int RAW_F4 = 2 * RAW_P;
+constexpr int V_F4 = 16 * 2 * 32;
+constexpr int A_F4 = 2 * PH * PW;      // 360 (pixel, k4) items per chunk
+constexpr int lds_bytes(int nt)
+{
+    const int stage = 16 * (2 * V_F4 + 2 * RAW_F4);
+    const int xch = 8 * 32 * (nt * 32 + 8) * 4;
+    return stage > xch ? stage : xch;
+}
+}  // namespace wino2
+
+// NTV = N tiles that hold real output channels (the last n-block of a layer whose cout is not a
+// multiple of NT*32 runs the NTV < NT instantiation: same packed layout, fewer accumulators).
+// Everything in the main loop is unconditional: a wave-uniform branch around a load or an MFMA
+// makes the compiler's s_waitcnt insertion pessimistic (it then waits for the loads it has just
+// issued), so profiling ablations are compile-time only (-DB2F_WINO2_ABLATE=bits).
+#ifndef B2F_WINO2_ABLATE
+#define B2F_WINO2_ABLATE 0
+#endif
+template <int NT, int NTV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino2(const ConvLaunch p)
+{
+    using namespace wino2;
+    constexpr int ABL = B2F_WINO2_ABLATE;   // 1 no transform, 2 no raw staging, 4 no B loads, 8 no MFMAs
+    constexpr int NB = NT * 32;
+    constexpr int U_F4 = 16 * 2 * NB;
+    constexpr int XS = NB + 8;             // floats per (plane, tile) row of the output exchange
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
+    f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, half = lane >> 5;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int nb = blockIdx.y + p.nb0;
+    const int ox0 = tx_i * TW, oy0 = ty_i * TH;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
+
+    // ---- staging coordinates of the raw patch (fixed over chunks): item idx = tid + 256 i ----
+    int a_goff[2], a_pix[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int pix = idx >> 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        a_ok[i] = (idx < A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_goff[i] = a_ok[i] ? (gy * p.W + gx) : 0;
+        a_pix[i] = (idx < A_F4) ? pix : -1;
+    }
+    const int a_h = tid & 1;
+
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * U_F4;
+
+    f32x4 ra[2];
+#define W2_LOAD_RAW(c_)                                                                             \
+    do {                                                                                            \
+        const int c__ = (c_);                                                                       \
+        const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
+        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
+        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
+        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;                            \
+        const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
+        const float *ib = base + (size_t)img * istr + (size_t)cc * cstr + a_h * 4;                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
+            ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
+    } while (0)
+    // B operands of xi pair q (xi = 4w + 2q, 4w + 2q + 1) of chunk c_: lane (m, half) loads U[xi][k4 = half][nt*32 + m]
+#define W2_LOAD_U(dst_, c_, q_)                                                                     \
+    do {                                                                                            \
+        const f32x4 *wb = wsrc + (size_t)(c_) * U_F4 + b_off + (q_) * 4 * NB;                       \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                               \
+            _Pragma("unroll") for (int nt = 0; nt < NTV; ++nt) dst_[x * NTV + nt] = wb[x * 2 * NB + nt * 32]; \
+    } while (0)
+#define W2_WRITE_RAW(buf_)                                                                          \
+    do {                                                                                            \
+        f32x4 *r = Rb + (buf_) * RAW_F4 + a_h * RAW_P;                                              \
+        r[a_pix[0]] = a_ok[0] ? ra[0] : f32x4{0.f, 0.f, 0.f, 0.f};                                  \
+        if (a_pix[1] >= 0) r[a_pix[1]] = a_ok[1] ? ra[1] : f32x4{0.f, 0.f, 0.f, 0.f};               \
+    } while (0)
+
+    // input transform, thread = (tile t = tid & 31, row a = (tid >> 5) & 3, k4 = tid >> 7): reads the two
+    // patch rows that B^T row a combines (8 float4), writes V[4a + b][k4][t], b = 0..3 (4 float4)
+    const int t_tile = tid & 31, t_a = (tid >> 5) & 3, t_k4 = tid >> 7;
+    const int t_r0 = (t_a == 0) ? 0 : 1;                 // a=0: d0-d2, a=1: d1+d2, a=2: d2-d1, a=3: d1-d3
+    const int t_r1 = (t_a == 3) ? 3 : 2;
+    const float t_s0 = (t_a == 2) ? -1.f : 1.f;
+    const float t_s1 = (t_a == 1 || t_a == 2) ? 1.f : -1.f;
+    const int t_src0 = t_k4 * RAW_P + (2 * (t_tile >> 3) + t_r0) * PW + 2 * (t_tile & 7);
+    const int t_src1 = t_k4 * RAW_P + (2 * (t_tile >> 3) + t_r1) * PW + 2 * (t_tile & 7);
+    const int t_dst = (t_a * 4 * 2 + t_k4) * 32 + t_tile;   // float4 index of V[xi = 4a][k4][t]; xi+1 -> +64
+
+    f32x16 acc[4][NTV];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int nt = 0; nt < NTV; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][nt][r] = 0.f;
+
+    const int a_off = (4 * wave * 2 + half) * 32 + m;        // V[xi = 4w][k4 = half][tile m]; xi+1 -> +64
+    const int b_off = (4 * wave * 2 + half) * NB + m;        // U[xi = 4w][k4 = half][co m];   xi+1 -> +2*NB
+    f32x4 b0[2 * NTV], b1[2 * NTV];
+
+    // ---- prologue: raw(0), raw(1) and the first B pair in flight together ----
+    {
+        f32x4 rb1[2];
+        W2_LOAD_RAW(min(1, nchunks - 1));
+        rb1[0] = ra[0]; rb1[1] = ra[1];
+        W2_LOAD_RAW(0);
+        W2_LOAD_U(b0, 0, 0);
+        W2_WRITE_RAW(0);
+        ra[0] = rb1[0]; ra[1] = rb1[1];
+        W2_WRITE_RAW(1);
+    }
+    __syncthreads();
+    {
+        const f32x4 *r = Rb;
+        f32x4 *v = Vb + t_dst;
+        f32x4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = t_s0 * r[t_src0 + j] + t_s1 * r[t_src1 + j];
+        v[0] = w[0] - w[2]; v[64] = w[1] + w[2]; v[128] = w[2] - w[1]; v[192] = w[1] - w[3];
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        // Branch-free, hand-ordered body (see the 512-thread kernel): loads and all LDS reads first,
+        // MFMAs of xi pair 0, transform of chunk c+1, MFMAs of xi pair 1, staging of raw(c+2), barrier.
+        if (!(ABL & 4)) W2_LOAD_U(b1, c, 1);
+        if (!(ABL & 2)) W2_LOAD_RAW(min(c + 2, nchunks - 1));
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
+        f32x4 av[4], tr0[4], tr1[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) av[x] = Vc[x * 64];
+        {
+            const f32x4 *r = Rb + ((c + 1) & 1) * RAW_F4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tr0[j] = r[t_src0 + j]; tr1[j] = r[t_src1 + j]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8)) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NTV; ++nt)
+                        acc[x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], b0[x * NTV + nt][j], acc[x][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) {
+            f32x4 *v = Vb + ((c + 1) & 1) * V_F4 + t_dst;
+            f32x4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = t_s0 * tr0[j] + t_s1 * tr1[j];
+            v[0] = w[0] - w[2]; v[64] = w[1] + w[2]; v[128] = w[2] - w[1]; v[192] = w[1] - w[3];
+        }
+        if (!(ABL & 4)) W2_LOAD_U(b0, min(c + 1, nchunks - 1), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8)) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NTV; ++nt)
+                        acc[2 + x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2 + x][j], b1[x * NTV + nt][j], acc[2 + x][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 2)) W2_WRITE_RAW(c & 1);
+        __syncthreads();
+    }
+#undef W2_LOAD_RAW
+#undef W2_LOAD_U
+#undef W2_WRITE_RAW
+
+    // ---- output: T[a][j] = sum_b A^T[j][b] M[a][b] in registers (wave = row a), exchange through
+    // LDS [a][j][tile][co], then Y[i][j] = sum_a A^T[i][a] T[a][j] + bias (+ LeakyReLU) ----
+    float *X = reinterpret_cast<float *>(smem);   // staging buffers are dead (barrier at loop end)
+#pragma unroll
+    for (int nt = 0; nt < NTV; ++nt) {
+        const f32x16 t0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
+        const f32x16 t1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (r & 3) + 8 * (r >> 2) + 4 * half;
+            X[((wave * 2 + 0) * 32 + t) * XS + nt * 32 + m] = t0[r];
+            X[((wave * 2 + 1) * 32 + t) * XS + nt * 32 + m] = t1[r];
+        }
+    }
+    __syncthreads();
+    float *ob = p.out + (size_t)img * p.out_img_stride;
+    const bool vec_ok = ((p.out_pix_stride | (int)p.out_chunk_stride) & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < NTV; ++it) {
+        const int idx = tid + it * 256;
+        const int o_cq = idx % (NTV * 8), o_t = idx / (NTV * 8);
+        const int co0 = nb * NB + 4 * o_cq;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+        f32x4 mm[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                mm[a][j] = *reinterpret_cast<const f32x4 *>(X + ((a * 2 + j) * 32 + o_t) * XS + 4 * o_cq);
+        const int oy = oy0 + 2 * (o_t >> 3), ox = ox0 + 2 * (o_t & 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = bias + (i == 0 ? (mm[0][j] + mm[1][j] + mm[2][j]) : (mm[1][j] - mm[2][j] - mm[3][j]));
+                if (p.leaky) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                }
+                if (oy + i < p.Ho && ox + j < p.Wo && co0 < p.cout) {
+                    float *dst = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co0 & 7);
+                    if (vec_ok && co0 + 3 < p.cout) {
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co0 + e < p.cout)
+                                ob[(size_t)((co0 + e) >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + ((co0 + e) & 7)] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int NTV>
+static hipError_t launch_wino2_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
+{
+    using namespace wino2;
+    constexpr int lds = lds_bytes(NT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino2<NT, NTV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvLaunch q = p;
+    q.nb0 = nb0;
+    const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    dim3 grid((unsigned)(tiles * p.nimg), (unsigned)nblk);
+    hipLaunchKernelGGL((conv3x3_wino2<NT, NTV>), grid, dim3(256), lds, s, q);
+    return hipGetLastError();
+}
+
 template <int NT>
 static hipError_t launch_wino_t(const ConvLaunch &p, hipStream_t s)
 {
@@ -317,6 +599,18 @@ hipError_t launch_conv3x3_wino(const ConvLaunch &p_in, hipStream_t s)
     ConvLaunch p = p_in;
     p.ablate = ablate;
     if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return hipErrorInvalidValue;
+    static const int gen = getenv("B2F_WINO_GEN") ? atoi(getenv("B2F_WINO_GEN")) : 2;
+    if (gen == 2) {
+        if (p.nt == 1) return launch_wino2_t<1, 1>(p, 0, p.nblk, s);
+        if (p.nt != 2) return hipErrorInvalidValue;
+        // n-blocks whose two N tiles both hold real channels, then the half-empty last one (cout = 96)
+        const int nfull = p.cout / 64, part = (p.cout % 64) ? 1 : 0;
+        const bool part_full = (p.cout % 64) > 32;
+        hipError_t e = hipSuccess;
+        if (nfull + (part_full ? 1 : 0) > 0) e = launch_wino2_t<2, 2>(p, 0, nfull + (part_full ? 1 : 0), s);
+        if (e == hipSuccess && part && !part_full) e = launch_wino2_t<2, 1>(p, nfull, 1, s);
+        return e;
+    }
     if (p.nt == 1) return launch_wino_t<1>(p, s);
     if (p.nt == 2) return launch_wino_t<2>(p, s);
     return hipErrorInvalidValue;
