@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libb2f.so")
+# B2F_LIB: profiling builds of the same library (tools/build_variant.py), never a different backend
+SO_PATH = os.environ.get("B2F_LIB") or os.path.join(_HERE, "libb2f.so")
 _lib = None
 
 c_float_p = C.POINTER(C.c_float)

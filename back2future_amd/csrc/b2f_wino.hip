@@ -310,7 +310,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino(const ConvLaunch p)
 namespace wino2 {
 constexpr int TH = 8, TW = 16;
 constexpr int PH = TH + 2, PW = TW + 2;
-constexpr int RAW_P = 184;             // float4 per k4 plane (10*18 = 180 pixels, padded)
+constexpr int RAW_P = 256;             // float4 per k4 plane: 10*18 = 180 pixels + dummy slots, so that every one
+                                       // of the 2 x 256 staging items has its own slot and the writes need no guard
 constexpr int RAW_F4 = 2 * RAW_P;
 constexpr int V_F4 = 16 * 2 * 32;
 constexpr int A_F4 = 2 * PH * PW;      // 360 (pixel, k4) items per chunk
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int gy = iy0 + py, gx = ix0 + px;
         a_ok[i] = (idx < A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         a_goff[i] = a_ok[i] ? (gy * p.W + gx) : 0;
-        a_pix[i] = (idx < A_F4) ? pix : -1;
+        a_pix[i] = pix;
     }
     const int a_h = tid & 1;
 
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     do {                                                                                            \
         f32x4 *r = Rb + (buf_) * RAW_F4 + a_h * RAW_P;                                              \
         r[a_pix[0]] = a_ok[0] ? ra[0] : f32x4{0.f, 0.f, 0.f, 0.f};                                  \
-        if (a_pix[1] >= 0) r[a_pix[1]] = a_ok[1] ? ra[1] : f32x4{0.f, 0.f, 0.f, 0.f};               \
+        r[a_pix[1]] = a_ok[1] ? ra[1] : f32x4{0.f, 0.f, 0.f, 0.f};                                  \
     } while (0)
 
     // input transform, thread = (tile t = tid & 31, row a = (tid >> 5) & 3, k4 = tid >> 7): reads the two
@@ -462,7 +463,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < 4; ++j) { tr0[j] = r[t_src0 + j]; tr1[j] = r[t_src1 + j]; }
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 8)) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -472,7 +472,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int nt = 0; nt < NTV; ++nt)
                         acc[x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], b0[x * NTV + nt][j], acc[x][nt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 1)) {
             f32x4 *v = Vb + ((c + 1) & 1) * V_F4 + t_dst;
             f32x4 w[4];
@@ -481,7 +480,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             v[0] = w[0] - w[2]; v[64] = w[1] + w[2]; v[128] = w[2] - w[1]; v[192] = w[1] - w[3];
         }
         if (!(ABL & 4)) W2_LOAD_U(b0, min(c + 1, nchunks - 1), 0);
-        __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 8)) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -491,8 +489,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int nt = 0; nt < NTV; ++nt)
                         acc[2 + x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2 + x][j], b1[x * NTV + nt][j], acc[2 + x][nt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 2)) W2_WRITE_RAW(c & 1);
+        // Issue order of the block above, spelled out for the scheduler: fp32 MFMAs and other waves'
+        // VALU / memory instructions do NOT overlap on a SIMD (measured: ablations are additive even
+        // with two independent blocks per CU), so everything else must sit in the 64-cycle shadow of
+        // this wave's own MFMAs: one MFMA, then a few independent non-MFMA instructions, 32 times.
+        if (ABL == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // A operands
+#pragma unroll
+            for (int i = 0; i < 16 * NTV; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                if (i < 2 * NTV + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // B(q=1), raw loads
+                else if (i >= 8 * NTV && i < 10 * NTV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // B(q=0) of c+1
+                if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // transform sources
+                if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, NTV == 2 ? 3 : 6, 0);      // transform / staging VALU
+                if (i >= 16 * NTV - 8 && i < 16 * NTV - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // V and raw writes
+            }
+        }
         __syncthreads();
     }
 #undef W2_LOAD_RAW
