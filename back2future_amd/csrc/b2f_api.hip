@@ -448,7 +448,6 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.out_img_stride = (long)(hw * kCvRec);
         cl.out_chunk_stride = (long)(hw * 8);
         cl.out_pix_stride = 8;
-        cl.ablate = 0;
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
         {
             Scope sc(c, s, "warp_costvol", cap);
@@ -972,7 +971,6 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     cl.flow_b = nullptr;
     cl.k = k; cl.out = dcv.p;
     cl.out_img_stride = (long)(hw * kCvRec); cl.out_chunk_stride = 8; cl.out_pix_stride = kCvRec;
-    cl.ablate = 0;
     cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
     HIPCHK(launch_warp_costvol(cl, c->stream));
     std::vector<float> rec((size_t)B * hw * kCvRec);

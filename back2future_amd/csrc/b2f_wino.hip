@@ -331,6 +331,19 @@ constexpr int lds_bytes(int nt)
 #ifndef B2F_WINO2_ABLATE
 #define B2F_WINO2_ABLATE 0
 #endif
+// Main-loop schedule: 0 = phases kept apart by scheduling barriers (loads + LDS reads | MFMAs of xi
+// pair 0 | transform | MFMAs of xi pair 1 | staging), 1 = one MFMA then a few non-MFMA instructions
+// (sched_group_barrier pipeline).  Measured: 0 is 16 % faster -- on gfx950 VALU instructions do not
+// execute in the shadow of an fp32 MFMA (tools/mfma_overlap.hip), so interleaving buys nothing and
+// shortens the distance between a load and its use.
+#ifndef B2F_WINO2_SCHED
+#define B2F_WINO2_SCHED 0
+#endif
+#if B2F_WINO2_SCHED == 0
+#define W2_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define W2_PHASE() do {} while (0)
+#endif
 template <int NT, int NTV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wino2(const ConvLaunch p)
 {
@@ -463,6 +476,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < 4; ++j) { tr0[j] = r[t_src0 + j]; tr1[j] = r[t_src1 + j]; }
         }
+        W2_PHASE();
         if (!(ABL & 8)) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int nt = 0; nt < NTV; ++nt)
                         acc[x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], b0[x * NTV + nt][j], acc[x][nt], 0, 0, 0);
         }
+        W2_PHASE();
         if (!(ABL & 1)) {
             f32x4 *v = Vb + ((c + 1) & 1) * V_F4 + t_dst;
             f32x4 w[4];
@@ -480,6 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             v[0] = w[0] - w[2]; v[64] = w[1] + w[2]; v[128] = w[2] - w[1]; v[192] = w[1] - w[3];
         }
         if (!(ABL & 4)) W2_LOAD_U(b0, min(c + 1, nchunks - 1), 0);
+        W2_PHASE();
         if (!(ABL & 8)) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
@@ -489,12 +505,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int nt = 0; nt < NTV; ++nt)
                         acc[2 + x][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2 + x][j], b1[x * NTV + nt][j], acc[2 + x][nt], 0, 0, 0);
         }
+        W2_PHASE();
         if (!(ABL & 2)) W2_WRITE_RAW(c & 1);
-        // Issue order of the block above, spelled out for the scheduler: fp32 MFMAs and other waves'
-        // VALU / memory instructions do NOT overlap on a SIMD (measured: ablations are additive even
-        // with two independent blocks per CU), so everything else must sit in the 64-cycle shadow of
-        // this wave's own MFMAs: one MFMA, then a few independent non-MFMA instructions, 32 times.
-        if (ABL == 0) {
+        // alternative issue order (B2F_WINO2_SCHED=1): one MFMA, then a few non-MFMA instructions, 32 times
+        if (B2F_WINO2_SCHED == 1) {
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // A operands
 #pragma unroll
             for (int i = 0; i < 16 * NTV; ++i) {
