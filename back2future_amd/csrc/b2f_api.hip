@@ -42,7 +42,7 @@ struct PackedConv {
     int nseg = 1;
     int chunks[2] = {0, 0};
     int cout = 0, nt = 1, nblk = 1;
-    bool wino = false;             // Winograd F(2x2,3x3) kernel (stride-1 layers)
+    int wino = 0;                  // 0 direct kernel, 2 Winograd F(2x2,3x3), 4 Winograd F(4x4,3x3) (stride-1 layers)
     size_t w_off = 0, b_off = 0;   // float offsets into wpk_dev
 };
 
@@ -167,6 +167,15 @@ bool use_wino()
     return on;
 }
 
+// Kernel choice for a stride-1 layer: F(4x4) for the wide layers (>= B2F_WINO4_MIN_COUT outputs,
+// default 64; 0 disables it), F(2x2) down to 16 outputs, direct kernel below.
+int wino_mode(int cout)
+{
+    static const int min4 = getenv("B2F_WINO4_MIN_COUT") ? atoi(getenv("B2F_WINO4_MIN_COUT")) : 64;
+    if (!use_wino() || cout < 16) return 0;
+    return (min4 > 0 && cout >= min4) ? 4 : 2;
+}
+
 int pack_all(b2f_ctx *c, const float *flat)
 {
     const size_t n = c->lay.size();
@@ -180,8 +189,9 @@ int pack_all(b2f_ctx *c, const float *flat)
         // stride-1 layers with >= 16 outputs run on the Winograd kernel (the first conv of a convUnit
         // has stride 2, the last decoder layer has 2 outputs: direct kernel)
         const bool stride1 = !(d.kind == KIND_FEAT && d.idx == 1);
-        p.wino = use_wino() && stride1 && d.co >= 16;
-        if (p.wino) wino_choose_tiles(d.co, &p.nt, &p.nblk);
+        p.wino = stride1 ? wino_mode(d.co) : 0;
+        if (p.wino == 4) { p.nt = 2; p.nblk = wino4_nblk(d.co); }
+        else if (p.wino == 2) wino_choose_tiles(d.co, &p.nt, &p.nblk);
         else conv_choose_tiles(d.co, &p.nt, &p.nblk);
         std::vector<int> &m = maps[i];
         if (d.kind != KIND_FEAT && d.idx == 1) {
@@ -214,7 +224,8 @@ int pack_all(b2f_ctx *c, const float *flat)
         }
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
         p.w_off = total;
-        total += p.wino ? wino_wpk_floats(chunks, p.nt, p.nblk) : conv_wpk_floats(chunks, p.nt, p.nblk);
+        total += p.wino == 4 ? wino4_wpk_floats(chunks, p.nblk)
+                 : p.wino == 2 ? wino_wpk_floats(chunks, p.nt, p.nblk) : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
     }
@@ -233,7 +244,10 @@ int pack_all(b2f_ctx *c, const float *flat)
         const ConvDesc &d = c->lay[i];
         const PackedConv &p = c->packed[i];
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
-        if (p.wino)
+        if (p.wino == 4)
+            wino4_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nblk,
+                               host.data() + p.w_off, host.data() + p.b_off);
+        else if (p.wino == 2)
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
                               host.data() + p.w_off, host.data() + p.b_off);
         else
@@ -351,9 +365,11 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.nimg = nimg;
     L.leaky = leaky;
     char name[32];
-    snprintf(name, sizeof name, p.wino ? "conv3x3_wino_nt%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.nt);
+    snprintf(name, sizeof name, p.wino == 4 ? "conv3x3_wino4_nt%d" : p.wino == 2 ? "conv3x3_wino_nt%d"
+                                : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.nt);
     Scope sc(c, s, name, cap);
-    if (p.wino) HIPCHK(launch_conv3x3_wino(L, s));
+    if (p.wino == 4) HIPCHK(launch_conv3x3_wino4(L, s));
+    else if (p.wino == 2) HIPCHK(launch_conv3x3_wino(L, s));
     else HIPCHK(launch_conv3x3(L, s));
     return 0;
 }
@@ -1029,11 +1045,15 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     const int chunks = (Ci + kCK - 1) / kCK, Cp = chunks * kCK;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int nt, nblk;
-    const bool wino = use_wino() && stride == 1 && Co >= 16;
-    if (wino) wino_choose_tiles(Co, &nt, &nblk);
+    const int wino = stride == 1 ? wino_mode(Co) : 0;
+    if (wino == 4) { nt = 2; nblk = wino4_nblk(Co); }
+    else if (wino == 2) wino_choose_tiles(Co, &nt, &nblk);
     else conv_choose_tiles(Co, &nt, &nblk);
-    std::vector<float> wpk(wino ? wino_wpk_floats(chunks, nt, nblk) : conv_wpk_floats(chunks, nt, nblk)), bpk((size_t)nblk * nt * 32);
-    if (wino) wino_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
+    std::vector<float> wpk(wino == 4 ? wino4_wpk_floats(chunks, nblk)
+                           : wino == 2 ? wino_wpk_floats(chunks, nt, nblk) : conv_wpk_floats(chunks, nt, nblk)),
+        bpk((size_t)nblk * nt * 32);
+    if (wino == 4) wino4_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nblk, wpk.data(), bpk.data());
+    else if (wino == 2) wino_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     else conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     DevBuf dpl, dx, dw, db, dy, dyp;
     const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
@@ -1050,7 +1070,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.wpk = dw.p; L.bias = db.p; L.out = dy.p;
     L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_chunk_stride = 8; L.out_pix_stride = Co; L.cout = Co;
     L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
-    if (wino) HIPCHK(launch_conv3x3_wino(L, c->stream));
+    if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
+    else if (wino == 2) HIPCHK(launch_conv3x3_wino(L, c->stream));
     else HIPCHK(launch_conv3x3(L, c->stream));
     HIPCHK(launch_nhwc_to_planar(dy.p, Co, Co, B, Ho, Wo, dyp.p, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -50,8 +50,8 @@ struct ConvLaunch {
     int H, W, Ho, Wo, stride;
     int nimg;
     int leaky;
+    long long *trace;   // profiling builds only (B2F_WINO_TRACE), nullptr otherwise
     int nb0;            // first n-block of this launch (Winograd kernel: a layer may be split over two launches)
-    int ablate;         // profiling only (B2F_WINO_ABLATE): 1 no transform, 2 no raw staging, 4 no B loads, 8 no MFMAs
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
 // floats needed for the packed weights of a conv with `cin_chunks` K-chunks
@@ -67,6 +67,13 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
 hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s);
 void wino_choose_tiles(int cout, int *nt, int *nblk);
 size_t wino_wpk_floats(int cin_chunks, int nt, int nblk);
+// ---- Winograd F(4x4,3x3) variant for the wide stride-1 layers (b2f_wino4.hip): 64 output channels per
+// n-block, weights packed by wino4_pack_weights ([nblk][chunk][xi 36][k4 2][64][4])
+hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s);
+int wino4_nblk(int cout);
+size_t wino4_wpk_floats(int cin_chunks, int nblk);
+void wino4_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks,
+                        int nblk, float *wpk, float *bpk);
 void wino_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
                        int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
 

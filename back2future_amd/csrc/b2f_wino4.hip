@@ -1,0 +1,496 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 MFMA for gfx950 (MI355X): the wide stride-1
+// nn.SpatialConvolution(Ci,Co,3,3,1,1,1,1) [+ LeakyReLU(0.2)] layers (Co >= 64) of
+// /root/reference/models/pwc.lua:62,78-82.  Same interface as b2f_wino.hip (chunk-planar in/out, up to two
+// input K-segments, bias + LeakyReLU fused) with 4x fewer MFMA MACs than the direct form:
+//
+//   Y(4x4) = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        d = 6x6 input tile, g = 3x3 filter
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]                (Lavin & Gray 2015)
+//
+// 36 independent GEMMs M_xi[tile][co] = sum_ci V_xi[tile][ci] U_xi[ci][co] (xi = 6a + b) on
+// v_mfma_f32_32x32x2_f32.  Why this form: on gfx950 nothing of the VALU kind overlaps an fp32 MFMA
+// (tools/mfma_overlap.hip), so time ~ MFMA count + the rest; F(4x4) needs 2.25 MACs per output
+// instead of 4 (F(2x2)) or 9 (direct), while its transforms cost about the same VALU work per
+// output pixel as F(2x2)'s.  Arithmetic differs from the direct form by fp32 rounding of the
+// transforms (coefficients up to 8): ~1e-6 relative on unit-scale data, end to end ~2e-7 absolute on
+// the flow (tests hold 1e-3).
+//
+// Block = 512 threads (8 waves, one block per CU) -> 16 x 32 output pixels = 4 x 8 tiles = 32 tiles
+// (one 32-row MFMA M tile), 64 output channels.  Wave w = g + 4 n owns xi = 9g .. 9g+8 for N tile n
+// (9 accumulators = 144 VGPRs).  K is walked in chunks of 8 input channels:
+//   raw  [2 buf][2 k4][18 rows][38] float4   input patch with halo, columns permuted (p & 3) * 9 + (p >> 2) so
+//                                           that the 8 tiles of a row read consecutive float4 (no bank conflicts)
+//   V    [2 buf][36 xi][2 k4][32 tiles] float4   transformed input (A operand)
+//   U    per lane straight from global (B operand), two xi ahead
+// One barrier per chunk (after xi 6, see the pipeline comment in the kernel).  Per xi the wave issues 4
+// MFMAs, then -- in order, pinned with scheduling barriers -- one slice of the other work, so that every
+// LDS / L2 latency sits under the MFMAs of the same wave: input transform (thread = (tile, k4, row a =
+// wave): 8 row-slices of 3 fused multiply-adds on float4, then the 6-point column pass and 6 b128
+// writes), staging of the raw patch (3 loads per thread, masked LDS writes 8 steps later).
+// Output: accumulators -> LDS [xi][tile][co] per N tile (144 KB), one thread per (tile, 4 channels,
+// output-column pair): A^T M A, bias, LeakyReLU, eight 16-byte stores.
+#include "b2f_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace b2f {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace wino4 {
+constexpr int TH = 16, TW = 32;             // output pixels per block
+constexpr int PH = TH + 2, PW = TW + 2;     // 18 x 34 input patch
+constexpr int RW = 38;                      // float4 per patch row in LDS; RW = 2 (mod 4) puts the two tile rows of a
+                                            // 16-lane ds_read_b128 group 128 B apart in bank space
+constexpr int RAW_P = PH * RW;              // 684 float4 per k4 plane
+constexpr int RAW_F4 = 2 * RAW_P;           // per raw buffer
+constexpr int V_F4 = 36 * 2 * 32;           // per V buffer
+constexpr int NITEM = 2 * PH * PW;          // 1224 (pixel, k4) staging items per chunk
+constexpr int U_F4 = 36 * 2 * 64;           // float4 of packed weights per (n-block, chunk)
+constexpr int STAGE_BYTES = 16 * (2 * V_F4 + 2 * RAW_F4);
+constexpr int XCH_BYTES = 36 * 32 * 32 * 4;
+constexpr int LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
+__device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2); }
+}  // namespace wino4
+
+#define W4_FMA(a_, b_, c_) __builtin_elementwise_fma((a_), (b_), (c_))
+
+// Profiling only: -DB2F_WINO_TRACE=1 records clock64() at five points of every main-loop iteration of a
+// few blocks (p.trace, set by the launcher when B2F_WINO_TRACE is in the environment).
+#ifndef B2F_WINO_TRACE
+#define B2F_WINO_TRACE 0
+#endif
+#if B2F_WINO_TRACE
+#define W4_T(k_) do { if (tr_on && lane == 0 && c < 32) tr_buf[(c * 5 + (k_))] = clock64(); } while (0)
+#else
+#define W4_T(k_) do {} while (0)
+#endif
+
+template <int NTV>
+__global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
+{
+    using namespace wino4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
+    f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int g = wave & 3, n = wave >> 2;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int nb = blockIdx.y + p.nb0;
+    const int ox0 = tx_i * TW, oy0 = ty_i * TH;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
+
+    // ---- staging of the raw patch: item idx = tid + 512 i -> (pixel idx >> 1, k4 = tid & 1), 3 per thread.
+    // Fixed over chunks: a 32-bit byte offset inside the (image, chunk) plane (both K segments have the
+    // same pixel stride, checked by the launcher) and the LDS slot.  Items outside the image (zero padding)
+    // or past the patch load offset 0 and never write LDS: padding slots are zeroed once here.
+    unsigned s_off[3];
+    int s_slot[3];
+    bool s_ok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * 512;
+        const int pix = idx >> 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const bool in_patch = idx < NITEM;
+        s_ok[i] = in_patch && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const unsigned gp = s_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;
+        s_off[i] = (gp * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
+        s_slot[i] = (tid & 1) * RAW_P + (in_patch ? py * RW + colpos(px) : 0);
+        if (in_patch && !s_ok[i]) { Rb[s_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; Rb[RAW_F4 + s_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const char *wsrc = reinterpret_cast<const char *>(p.wpk) + (size_t)nb * nchunks * U_F4 * 16;
+
+    f32x4 sr[3];
+#define W4_LOAD_RAW(c_)                                                                             \
+    do {                                                                                            \
+        const int c__ = (c_);                                                                       \
+        const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
+        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
+        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
+        const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
+        const char *ib = reinterpret_cast<const char *>(base + (size_t)img * istr + (size_t)cc * cstr); \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) sr[i] = *reinterpret_cast<const f32x4 *>(ib + s_off[i]); \
+    } while (0)
+#define W4_WRITE_RAW(buf_)                                                                          \
+    do {                                                                                            \
+        f32x4 *r = Rb + (buf_) * RAW_F4;                                                            \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) if (s_ok[i]) r[s_slot[i]] = sr[i];            \
+    } while (0)
+
+    // ---- input transform role: thread = (tile t = lane & 31, k4 = lane >> 5, row a = wave; waves 6, 7 redo
+    // row 5 and drop the result, so that all waves run the same instruction stream) ----
+    const int ta = wave < 6 ? wave : 5;
+    // row a of B^T as up to four (input row, coefficient) pairs
+    int r0, r1, r2, r3;
+    float c0, c1, c2, c3;
+    switch (ta) {
+    case 0: r0 = 0; r1 = 2; r2 = 4; r3 = 4; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; c3 = 1.f; break;
+    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
+    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; c3 = 1.f; break;
+    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
+    default: r0 = 1; r1 = 3; r2 = 5; r3 = 5; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    }
+    const int t_tile = lane & 31, t_k4 = lane >> 5;
+    const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
+    const int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
+    // coefficient pairs live in VGPRs: with a scalar operand the compiler emits two v_fma_f32 instead of one
+    // v_pk_fma_f32 (VALU instructions are what the loop pays for)
+    f32x2 t_cf[4] = {{c0, c0}, {c1, c1}, {c2, c2}, {c3, c3}};
+    asm volatile("" : "+v"(t_cf[0]), "+v"(t_cf[1]), "+v"(t_cf[2]), "+v"(t_cf[3]));
+    const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;        // float4 index of V[xi = 6a][k4][t]; xi+1 -> +64
+    const bool t_write = wave < 6;
+    f32x4 R[6], d[3];
+    // slice s = 2 r + h: input row r (of the four), columns 3h .. 3h+2 of the 6-wide tile window
+#define W4_T_READ(s_, rbuf_)                                                                        \
+    do {                                                                                            \
+        const f32x4 *rp = Rb + (rbuf_) * RAW_F4 + t_row[(s_) >> 1];                                 \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) d[k] = rp[colpos(3 * ((s_) & 1) + k)];       \
+    } while (0)
+#define W4_T_FMA(s_)                                                                                \
+    do {                                                                                            \
+        const f32x2 cf2 = t_cf[(s_) >> 1];                                                          \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                             \
+            f32x4 &Rk = R[3 * ((s_) & 1) + k];                                                      \
+            const f32x2 dlo = __builtin_shufflevector(d[k], d[k], 0, 1), dhi = __builtin_shufflevector(d[k], d[k], 2, 3); \
+            f32x2 lo, hi;                                                                           \
+            if (((s_) >> 1) == 0) { lo = cf2 * dlo; hi = cf2 * dhi; }                               \
+            else {                                                                                  \
+                lo = __builtin_elementwise_fma(cf2, dlo, __builtin_shufflevector(Rk, Rk, 0, 1));    \
+                hi = __builtin_elementwise_fma(cf2, dhi, __builtin_shufflevector(Rk, Rk, 2, 3));    \
+            }                                                                                       \
+            Rk = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);                                       \
+        }                                                                                           \
+        /* pin the slice here: without a side-effecting user instruction selection sinks the fmas to */ \
+        /* the column pass and all 24 raw float4 stay live (spills) */                              \
+        asm volatile("" : "+v"(R[3 * ((s_) & 1)]), "+v"(R[3 * ((s_) & 1) + 1]), "+v"(R[3 * ((s_) & 1) + 2])); \
+    } while (0)
+    // column pass: V[a][.] = R B, then the 6 b128 writes (waves 6, 7 masked)
+#define W4_T_COLS(vbuf_)                                                                            \
+    do {                                                                                            \
+        const f32x4 k4v = {4.f, 4.f, 4.f, 4.f}, k5v = {-5.f, -5.f, -5.f, -5.f}, km4 = {-4.f, -4.f, -4.f, -4.f}; \
+        const f32x4 k2v = {2.f, 2.f, 2.f, 2.f}, km2 = {-2.f, -2.f, -2.f, -2.f};                     \
+        const f32x4 v0 = W4_FMA(k5v, R[2], W4_FMA(k4v, R[0], R[4]));                                \
+        const f32x4 pq = W4_FMA(km4, R[2], R[4]), qq = W4_FMA(km4, R[1], R[3]);                     \
+        const f32x4 uu = R[4] - R[2], vv = R[3] - R[1];                                             \
+        const f32x4 v5 = W4_FMA(k5v, R[3], W4_FMA(k4v, R[1], R[5]));                                \
+        if (t_write) {                                                                              \
+            f32x4 *v = Vb + (vbuf_) * V_F4 + t_dst;                                                 \
+            v[0] = v0; v[64] = pq + qq; v[128] = pq - qq;                                           \
+            v[192] = W4_FMA(k2v, vv, uu); v[256] = W4_FMA(km2, vv, uu); v[320] = v5;                \
+        }                                                                                           \
+    } while (0)
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int x = 0; x < 9; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const bool mf_on = n < NTV;                                          // this wave's N tile holds real channels
+    const int a_off = (9 * g * 2 + half) * 32 + m;                       // V[xi = 9g][k4 = half][tile m]; xi+1 -> +64
+    const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u; // bytes: U[xi = 9g][k4 = half][co]; xi+1 -> +2048
+    f32x4 av[3], bv[3];
+#define W4_LOAD_U(slot_, c_, x_) bv[slot_] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)(c_) * (U_F4 * 16) + b_off + (x_) * 2048)
+
+    // Software pipeline (Tr(k) = input transform of chunk k -> V[k & 1], raw(k) = its patch in raw buffer k & 1):
+    //   iteration c, xi steps 0..5 : MFMAs of xi (A operand read one step ahead, B two steps ahead),
+    //                                slices 2..7 of Tr(c+1)
+    //                xi step  6    : MFMAs, column pass of Tr(c+1) -> V[(c+1) & 1], raw(c+2) -> LDS, A operands of
+    //                                xi 7, 8 fetched, BARRIER
+    //                xi steps 7, 8 : MFMAs, A operands of xi 0, 1 of chunk c+1, slices 0, 1 of Tr(c+2); global loads
+    //                                of raw(c+3)
+    // so nothing that follows the barrier depends on LDS data written just before it.
+    // ---- prologue: raw(0), raw(1) -> LDS; Tr(0) -> V[0]; slices 0, 1 of Tr(1); raw(2) in flight; B of xi 0, 1 ----
+    {
+        f32x4 keep[3];
+        W4_LOAD_RAW(min(1, nchunks - 1));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep[i] = sr[i];
+        W4_LOAD_RAW(0);
+        if (NTV == 2 || mf_on) { W4_LOAD_U(0, 0, 0); W4_LOAD_U(1, 0, 1); }
+        W4_WRITE_RAW(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sr[i] = keep[i];
+        W4_WRITE_RAW(1);
+        W4_LOAD_RAW(min(2, nchunks - 1));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s); }
+    W4_T_COLS(0);
+    W4_T_READ(0, 1); W4_T_FMA(0);
+    W4_T_READ(1, 1); W4_T_FMA(1);
+    W4_T_READ(2, 1);
+    __syncthreads();
+    av[0] = Vb[a_off];
+    av[1] = Vb[a_off + 64];
+
+#if B2F_WINO_TRACE
+    const int tr_slot = blockIdx.x == 300 ? 0 : blockIdx.x == 301 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1456 ? 3 : -1;
+    const bool tr_on = p.trace && tr_slot >= 0 && blockIdx.y == 0;
+    long long *tr_buf = p.trace + (tr_on ? (tr_slot * 8 + wave) * 160 : 0);
+#endif
+    for (int c = 0; c < nchunks; ++c) {
+        W4_T(0);
+        const int cn = min(c + 1, nchunks - 1);
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
+        const f32x4 *Vn = Vb + ((c + 1) & 1) * V_F4 + a_off;
+#pragma unroll
+        for (int x = 0; x < 9; ++x) {
+            // B operand two xi ahead (next chunk's for x >= 7); A operand one xi ahead (xi 8 two ahead, so that
+            // every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it)
+            if (NTV == 2 || mf_on) {
+                if (x + 2 < 9) W4_LOAD_U((x + 2) % 3, c, x + 2);
+                else W4_LOAD_U((x + 2) % 3, cn, x + 2 - 9);
+            }
+            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];
+            if (x == 6) av[8 % 3] = Vc[8 * 64];
+            if (x == 7) av[0] = Vn[0];
+            if (x == 8) av[1] = Vn[64];
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTV == 2 || mf_on) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[x % 3][j], acc[x], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (x < 6) {
+                // slice x + 2 of Tr(c+1) (its reads were issued one step ago), then the reads of the next slice
+                W4_T_FMA(x + 2);
+                if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);
+            } else if (x == 6) {
+                W4_T_COLS((c + 1) & 1);
+                W4_WRITE_RAW(c & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                W4_T(3);
+                __syncthreads();
+                W4_T(4);
+                W4_T_READ(0, c & 1);                       // Tr(c+2), raw(c+2) is in raw buffer c & 1
+                W4_LOAD_RAW(min(c + 3, nchunks - 1));
+            } else if (x == 7) {
+                W4_T_FMA(0);
+                W4_T_READ(1, c & 1);
+            } else {
+                W4_T_FMA(1);
+                W4_T_READ(2, c & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (x == 2) W4_T(1);
+            if (x == 5) W4_T(2);
+        }
+    }
+#undef W4_LOAD_RAW
+#undef W4_WRITE_RAW
+#undef W4_T_READ
+#undef W4_T_FMA
+#undef W4_T_COLS
+#undef W4_LOAD_U
+
+    // ---- output, one pass per N tile: the four waves of that tile write their accumulators to LDS
+    // X[xi][tile row][co 32] (tile rows t and t ^ 1 swapped when bit 2 of t is set: the two lane halves
+    // of a ds_write then hit different bank halves); then ALL 512 threads take one (tile, 4 couts,
+    // column pair) item each: the waves of the other N tile still hold their accumulators, so the
+    // item is kept small (columns {0,2} need only the sums M1+M2, M3+M4, columns {1,3} only the
+    // differences): A^T M A for 2 of the 4 output columns, bias, LeakyReLU, eight 16-byte stores ----
+    float *X = reinterpret_cast<float *>(smem);
+    float *ob = p.out + (size_t)img * p.out_img_stride;
+    const bool vec_ok = ((p.out_pix_stride | (int)p.out_chunk_stride) & 3) == 0;
+    const int o_jp = tid & 1, o_cq = (tid >> 1) & 7, o_t = tid >> 4;
+    const int o_xr = o_t ^ ((o_t >> 2) & 1);
+    const int oy = oy0 + 4 * (o_t >> 3), ox = ox0 + 4 * (o_t & 7);
+#pragma unroll 1
+    for (int pass = 0; pass < NTV; ++pass) {
+        if (n == pass) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = ((r & 3) + 8 * (r >> 2) + 4 * half) ^ half;
+                    X[((9 * g + x) * 32 + t) * 32 + m] = acc[x][r];
+                }
+        }
+        __syncthreads();
+        {
+            const int co0 = nb * 64 + pass * 32 + 4 * o_cq;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+            // column pair jp = 0: output columns 0 and 2 (T0 = M0 + s1 + s2, T2 = s1 + 4 s2 with s = sums),
+            //             jp = 1: output columns 1 and 3 (T1 = d1 + 2 d2, T3 = d1 + 8 d2 + M5 with d = differences)
+            const float *xp = X + o_xr * 32 + 4 * o_cq + (o_jp ? 5 : 0) * 1024;   // jp = 1 reads M5 instead of M0
+            const float sg = o_jp ? -1.f : 1.f;
+            const f32x4 sg4 = {sg, sg, sg, sg};
+            const float ka = o_jp ? 2.f : 1.f, kb = o_jp ? 8.f : 4.f;
+            const f32x4 ka4 = {ka, ka, ka, ka}, kb4 = {kb, kb, kb, kb};
+            f32x4 Ta[6], Tb[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const float *xa = X + o_xr * 32 + 4 * o_cq + (6 * a) * 1024;
+                const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xa + 1 * 1024), m2 = *reinterpret_cast<const f32x4 *>(xa + 2 * 1024);
+                const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xa + 3 * 1024), m4 = *reinterpret_cast<const f32x4 *>(xa + 4 * 1024);
+                const f32x4 me = *reinterpret_cast<const f32x4 *>(xp + (6 * a) * 1024);   // M0 (jp 0) or M5 (jp 1)
+                const f32x4 e1 = W4_FMA(sg4, m2, m1), e2 = W4_FMA(sg4, m4, m3);           // sums or differences
+                // jp 0: Ta = M0 + s1 + s2, Tb = s1 + 4 s2;   jp 1: Ta = d1 + 2 d2, Tb = d1 + 8 d2 + M5
+                const f32x4 ta = W4_FMA(ka4, e2, e1), tb = W4_FMA(kb4, e2, e1);
+                Ta[a] = o_jp ? ta : ta + me;
+                Tb[a] = o_jp ? tb + me : tb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 *Tq = q ? Tb : Ta;
+                const int j = o_jp + 2 * q;
+                const f32x4 s1 = Tq[1] + Tq[2], d1 = Tq[1] - Tq[2], s2 = Tq[3] + Tq[4], d2 = Tq[3] - Tq[4];
+                const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f};
+                f32x4 y[4];
+                y[0] = Tq[0] + s1 + s2;
+                y[1] = W4_FMA(k2, d2, d1);
+                y[2] = W4_FMA(k4, s2, s1);
+                y[3] = W4_FMA(k8, d2, d1) + Tq[5];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = y[i] + bias;
+                    if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
+                    if (oy + i < p.Ho && ox + j < p.Wo && co0 < p.cout) {
+                        float *dst = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co0 & 7);
+                        if (vec_ok && co0 + 3 < p.cout) {
+                            *reinterpret_cast<f32x4 *>(dst) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (co0 + e < p.cout)
+                                    ob[(size_t)((co0 + e) >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + ((co0 + e) & 7)] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NTV>
+static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
+{
+    using namespace wino4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4<NTV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvLaunch q = p;
+    q.nb0 = nb0;
+    q.trace = nullptr;
+#if B2F_WINO_TRACE
+    static long long *trace_dev = nullptr;
+    static int traced = 0;
+    const bool do_trace = getenv("B2F_WINO_TRACE") && traced < 1 && NTV == 2 && p.seg[0].nchunks == 16 && p.nseg == 1 && p.H * p.W >= 256 * 480;
+    if (do_trace) {
+        if (!trace_dev) hipMalloc(&trace_dev, 32 * 160 * sizeof(long long));
+        hipMemsetAsync(trace_dev, 0, 32 * 160 * sizeof(long long), s);
+        q.trace = trace_dev;
+    }
+#endif
+    const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    dim3 grid((unsigned)(tiles * p.nimg), (unsigned)nblk);
+    hipLaunchKernelGGL((conv3x3_wino4<NTV>), grid, dim3(512), LDS_BYTES, s, q);
+#if B2F_WINO_TRACE
+    if (do_trace) {
+        ++traced;
+        std::vector<long long> h(32 * 160);
+        hipStreamSynchronize(s);
+        hipMemcpy(h.data(), trace_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < 8; ++w) {
+                const long long *t = h.data() + (b * 8 + w) * 160;
+                fprintf(stderr, "wino4 trace block-slot %d wave %d (cycles since first stamp; top | xi 0-2 done | xi 3-5 | xi 6-7 | xi 8 + cols + raw written):\n", b, w);
+                for (int c = 0; c < 16; ++c)
+                    fprintf(stderr, "  c=%2d  %7lld %7lld %7lld %7lld %7lld\n", c, t[c * 5] - t[0], t[c * 5 + 1] - t[0], t[c * 5 + 2] - t[0],
+                            t[c * 5 + 3] - t[0], t[c * 5 + 4] - t[0]);
+            }
+    }
+#endif
+    return hipGetLastError();
+}
+
+bool wino4_supported(const ConvLaunch &p)
+{
+    if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
+    if (p.nseg > 1 && p.seg[1].pix_stride != p.seg[0].pix_stride) return false;
+    return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 4294967296.0;   // 32-bit byte offsets inside a plane
+}
+
+hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
+{
+    if (!wino4_supported(p)) return hipErrorInvalidValue;
+    // n-blocks of 64 channels whose two N tiles both hold real channels, then a half-empty last one
+    const int nfull = p.cout / 64, rem = p.cout % 64;
+    const int n2 = nfull + (rem > 32 ? 1 : 0);
+    hipError_t e = hipSuccess;
+    if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
+    if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino4_t<1>(p, nfull, 1, s);
+    return e;
+}
+
+int wino4_nblk(int cout) { return (cout + 63) / 64; }
+
+size_t wino4_wpk_floats(int cin_chunks, int nblk)
+{
+    return (size_t)nblk * cin_chunks * wino4::U_F4 * 4;
+}
+
+// U = G g G^T in double, rounded once to fp32; packed [nblk][chunk][xi 36][k4 2][64 co][4 ci]
+void wino4_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks,
+                        int nblk, float *wpk, float *bpk)
+{
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    std::vector<double> U((size_t)Co * Ci * 36);
+    for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float *gk = w + ((size_t)co * Ci + ci) * 9;
+            double t[6][3];
+            for (int a = 0; a < 6; ++a)
+                for (int v = 0; v < 3; ++v) t[a][v] = G[a][0] * gk[0 * 3 + v] + G[a][1] * gk[1 * 3 + v] + G[a][2] * gk[2 * 3 + v];
+            for (int a = 0; a < 6; ++a)
+                for (int bq = 0; bq < 6; ++bq)
+                    U[((size_t)co * Ci + ci) * 36 + a * 6 + bq] = t[a][0] * G[bq][0] + t[a][1] * G[bq][1] + t[a][2] * G[bq][2];
+        }
+    for (int nbk = 0; nbk < nblk; ++nbk)
+        for (int c = 0; c < cin_chunks; ++c)
+            for (int xi = 0; xi < 36; ++xi)
+                for (int h = 0; h < 2; ++h)
+                    for (int nn = 0; nn < 64; ++nn)
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = nbk * 64 + nn;
+                            const int k = c * kCK + h * 4 + j;
+                            const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
+                            float v = 0.f;
+                            if (co < Co && ci >= 0) v = (float)U[((size_t)co * Ci + ci) * 36 + xi];
+                            wpk[((((((size_t)nbk * cin_chunks + c) * 36 + xi) * 2 + h) * 64 + nn) * 4) + j] = v;
+                        }
+    for (int i = 0; i < nblk * 64; ++i) bpk[i] = i < Co ? b[i] : 0.f;
+}
+
+}  // namespace b2f

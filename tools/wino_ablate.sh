@@ -1,7 +1,7 @@
 #!/bin/bash
 # Ablation of the gen-2 Winograd kernel (profiling only; results are wrong with ablate != 0).
 # Variants are compile-time (a runtime branch around loads/MFMAs pessimizes s_waitcnt placement):
-#   for a in 1 2 4 8 3 7 9 15; do python tools/build_variant.py wabl$a b2f_wino.hip -DB2F_WINO2_ABLATE=$a; done
+#   for a in 1 2 4 8 3 7 9 15; do python tools/build_variant.py wabl$a b2f_wino.hip -DB2F_WINO_ABLATE=$a; done
 # built on the CPU box; the .so files travel with gpurun.
 for a in 0 1 2 4 8 3 7 9 15; do
   lib=back2future_amd/libb2f_wabl$a.so
