@@ -154,10 +154,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const int t_tile = lane & 31, t_k4 = lane >> 5;
     const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
     const int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
-    // coefficient pairs live in VGPRs: with a scalar operand the compiler emits two v_fma_f32 instead of one
-    // v_pk_fma_f32 (VALU instructions are what the loop pays for)
-    f32x2 t_cf[4] = {{c0, c0}, {c1, c1}, {c2, c2}, {c3, c3}};
-    asm volatile("" : "+v"(t_cf[0]), "+v"(t_cf[1]), "+v"(t_cf[2]), "+v"(t_cf[3]));
+    const float t_cf[4] = {c0, c1, c2, c3};     // wave-uniform (SGPRs)
     const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;        // float4 index of V[xi = 6a][k4][t]; xi+1 -> +64
     const bool t_write = wave < 6;
     f32x4 R[6], d[3];
@@ -167,23 +164,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         const f32x4 *rp = Rb + (rbuf_) * RAW_F4 + t_row[(s_) >> 1];                                 \
         _Pragma("unroll") for (int k = 0; k < 3; ++k) d[k] = rp[colpos(3 * ((s_) & 1) + k)];       \
     } while (0)
+    // Written as v_pk_* inline asm: hipcc unpacks packed fp32 ops that follow an MFMA into two scalar ones (it
+    // assumes they co-issue with the MFMA; behind an fp32 MFMA they do not), and VALU instructions are what
+    // this loop pays for.  The asm also pins the slice here (otherwise instruction selection sinks the fmas to
+    // the column pass and all 24 raw float4 stay live).
 #define W4_T_FMA(s_)                                                                                \
     do {                                                                                            \
-        const f32x2 cf2 = t_cf[(s_) >> 1];                                                          \
+        const float cf = t_cf[(s_) >> 1];                                                           \
+        const f32x2 cf2 = {cf, cf};                                                                 \
         _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                             \
             f32x4 &Rk = R[3 * ((s_) & 1) + k];                                                      \
             const f32x2 dlo = __builtin_shufflevector(d[k], d[k], 0, 1), dhi = __builtin_shufflevector(d[k], d[k], 2, 3); \
-            f32x2 lo, hi;                                                                           \
-            if (((s_) >> 1) == 0) { lo = cf2 * dlo; hi = cf2 * dhi; }                               \
-            else {                                                                                  \
-                lo = __builtin_elementwise_fma(cf2, dlo, __builtin_shufflevector(Rk, Rk, 0, 1));    \
-                hi = __builtin_elementwise_fma(cf2, dhi, __builtin_shufflevector(Rk, Rk, 2, 3));    \
+            f32x2 lo = __builtin_shufflevector(Rk, Rk, 0, 1), hi = __builtin_shufflevector(Rk, Rk, 2, 3); \
+            if (((s_) >> 1) == 0) {                                                                 \
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "s"(cf2), "v"(dlo));            \
+                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "s"(cf2), "v"(dhi));            \
+            } else {                                                                                \
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "s"(cf2), "v"(dlo));        \
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "s"(cf2), "v"(dhi));        \
             }                                                                                       \
             Rk = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);                                       \
         }                                                                                           \
-        /* pin the slice here: without a side-effecting user instruction selection sinks the fmas to */ \
-        /* the column pass and all 24 raw float4 stay live (spills) */                              \
-        asm volatile("" : "+v"(R[3 * ((s_) & 1)]), "+v"(R[3 * ((s_) & 1) + 1]), "+v"(R[3 * ((s_) & 1) + 2])); \
     } while (0)
     // column pass: V[a][.] = R B, then the 6 b128 writes (waves 6, 7 masked)
 #define W4_T_COLS(vbuf_)                                                                            \
@@ -262,7 +263,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             // every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it)
             if (NTV == 2 || mf_on) {
                 if (x + 2 < 9) W4_LOAD_U((x + 2) % 3, c, x + 2);
-                else W4_LOAD_U((x + 2) % 3, cn, x + 2 - 9);
+                else if (x == 8) W4_LOAD_U(1, cn, 1);
+                // (the load of xi 0 of the next chunk, due at x == 7, is issued at the end of step 6, ahead of the
+                // raw loads: s_waitcnt vmcnt is in order, every B operand fetched after them waits for HBM)
             }
             if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];
             if (x == 6) av[8 % 3] = Vc[8 * 64];
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             } else if (x == 6) {
                 W4_T_COLS((c + 1) & 1);
                 W4_WRITE_RAW(c & 1);
+                if (NTV == 2 || mf_on) W4_LOAD_U(0, cn, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 W4_T(3);
                 __syncthreads();
