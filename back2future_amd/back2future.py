@@ -80,7 +80,7 @@ class Model(object):
         _lib.check(_lib.lib().b2f_profile_reset(self._h))
 
     def profile_read(self):
-        cap = 64
+        cap = 256
         names = C.create_string_buffer(32 * cap)
         ms = (C.c_double * cap)()
         cnt = (C.c_longlong * cap)()

@@ -173,7 +173,7 @@ int wino_mode(int cout)
 {
     static const int min4 = getenv("B2F_WINO4_MIN_COUT") ? atoi(getenv("B2F_WINO4_MIN_COUT")) : 64;
     if (!use_wino() || cout < 16) return 0;
-    return (min4 > 0 && cout >= min4) ? 4 : 2;
+    return (min4 > 0 && cout >= min4 && cout % 4 == 0) ? 4 : 2;   // F(4x4) stores 4 channels at a time
 }
 
 int pack_all(b2f_ctx *c, const float *flat)
@@ -364,9 +364,14 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.out_pix_stride = 8;
     L.nimg = nimg;
     L.leaky = leaky;
-    char name[32];
-    snprintf(name, sizeof name, p.wino == 4 ? "conv3x3_wino4_nt%d" : p.wino == 2 ? "conv3x3_wino_nt%d"
-                                : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.nt);
+    char name[48];
+    static const bool per_layer = getenv("B2F_PROFILE_LAYERS") != nullptr;   // one profile row per (layer shape, map size)
+    if (per_layer)
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", p.wino == 4 ? "W4" : p.wino == 2 ? "W2" : stride == 1 ? "D1" : "D2",
+                 (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
+    else
+        snprintf(name, sizeof name, p.wino == 4 ? "conv3x3_wino4_nt%d" : p.wino == 2 ? "conv3x3_wino_nt%d"
+                                    : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.nt);
     Scope sc(c, s, name, cap);
     if (p.wino == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (p.wino == 2) HIPCHK(launch_conv3x3_wino(L, s));

@@ -28,8 +28,8 @@
 // LDS / L2 latency sits under the MFMAs of the same wave: input transform (thread = (tile, k4, row a =
 // wave): 8 row-slices of 3 fused multiply-adds on float4, then the 6-point column pass and 6 b128
 // writes), staging of the raw patch (3 loads per thread, masked LDS writes 8 steps later).
-// Output: accumulators -> LDS [xi][tile][co] per N tile (144 KB), one thread per (tile, 4 channels,
-// output-column pair): A^T M A, bias, LeakyReLU, eight 16-byte stores.
+// Output: accumulators -> LDS [xi][tile][co] per N tile (144 KB), one thread per (tile, 4 channels):
+// A^T M A, bias, LeakyReLU, sixteen 16-byte stores.
 #include "b2f_internal.h"
 
 #include <cstdio>
@@ -71,6 +71,56 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 #define W4_T(k_) do {} while (0)
 #endif
 
+// Output stage of one N tile (32 channels), run by the 256 threads of the four waves that own it after they
+// have dumped their accumulators to X[xi][tile row][co 32]: item = (tile, 4 channels), A^T M A, bias,
+// LeakyReLU, sixteen 16-byte stores.
+// TAG only labels the two inlined copies (asm comments): identical copies get merged back into one shared
+// block by the compiler, and the accumulators of the second tile would be live (spilled) across it again.
+template <int TAG>
+__device__ __forceinline__ void wino4_output_tile(const float *X, const ConvLaunch &p, int idx, int co_base, int oy0, int ox0, float *ob)
+{
+    const int o_t = idx >> 3, o_cq = idx & 7;
+    const int xr = o_t ^ ((o_t >> 2) & 1);
+    const int co0 = co_base + 4 * o_cq;
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+    const float *xp = X + xr * 32 + 4 * o_cq;
+    const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f};
+    f32x4 T[6][4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        f32x4 M[6];
+        asm volatile("; output stage of N tile %0" ::"n"(TAG));
+#pragma unroll
+        for (int b = 0; b < 6; ++b) M[b] = *reinterpret_cast<const f32x4 *>(xp + (6 * a + b) * 1024);
+        const f32x4 s1 = M[1] + M[2], d1 = M[1] - M[2], s2 = M[3] + M[4], d2 = M[3] - M[4];
+        T[a][0] = M[0] + s1 + s2;
+        T[a][1] = W4_FMA(k2, d2, d1);
+        T[a][2] = W4_FMA(k4, s2, s1);
+        T[a][3] = W4_FMA(k8, d2, d1) + M[5];
+    }
+    const int oy = oy0 + 4 * (o_t >> 3), ox = ox0 + 4 * (o_t & 7);
+    // 16-byte stores; the launcher guarantees 4-aligned strides and cout % 4 == 0
+    float *obase = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co0 & 7);
+    const bool col_ok = co0 < p.cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 s1 = T[1][j] + T[2][j], d1 = T[1][j] - T[2][j], s2 = T[3][j] + T[4][j], d2 = T[3][j] - T[4][j];
+        f32x4 y[4];
+        y[0] = T[0][j] + s1 + s2;
+        y[1] = W4_FMA(k2, d2, d1);
+        y[2] = W4_FMA(k4, s2, s1);
+        y[3] = W4_FMA(k8, d2, d1) + T[5][j];
+        asm volatile("; output stage of N tile %0" ::"n"(TAG));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = y[i] + bias;
+            if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
+            if (col_ok && oy + i < p.Ho && ox + j < p.Wo)
+                *reinterpret_cast<f32x4 *>(obase + (size_t)(i * p.Wo + j) * p.out_pix_stride) = v;
+        }
+    }
+}
+
 template <int NTV>
 __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 {
@@ -79,6 +129,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
     f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
 
+#if B2F_WINO_TRACE
+    const long long t_start = clock64();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,6 +305,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const bool tr_on = p.trace && tr_slot >= 0 && blockIdx.y == 0;
     long long *tr_buf = p.trace + (tr_on ? (tr_slot * 8 + wave) * 160 : 0);
 #endif
+#if B2F_WINO_TRACE
+    if (tr_on && lane == 0) { tr_buf[150] = t_start; tr_buf[151] = clock64(); }
+#endif
     for (int c = 0; c < nchunks; ++c) {
         W4_T(0);
         const int cn = min(c + 1, nchunks - 1);
@@ -311,85 +367,51 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #undef W4_T_COLS
 #undef W4_LOAD_U
 
-    // ---- output, one pass per N tile: the four waves of that tile write their accumulators to LDS
-    // X[xi][tile row][co 32] (tile rows t and t ^ 1 swapped when bit 2 of t is set: the two lane halves
-    // of a ds_write then hit different bank halves); then ALL 512 threads take one (tile, 4 couts,
-    // column pair) item each: the waves of the other N tile still hold their accumulators, so the
-    // item is kept small (columns {0,2} need only the sums M1+M2, M3+M4, columns {1,3} only the
-    // differences): A^T M A for 2 of the 4 output columns, bias, LeakyReLU, eight 16-byte stores ----
+    // ---- output, one N tile at a time (LDS holds the 36 planes of 32 channels: 144 KB): the four waves of
+    // the tile write their accumulators to X[xi][tile row][co 32] (tile rows t and t ^ 1 swapped when bit 2
+    // of t is set: the two lane halves of a ds_write then hit different bank halves); the output stage of
+    // BOTH tiles is run by the waves of tile 0, whose accumulators are dead by then (in the code path of the
+    // tile-1 waves the register allocator keeps the 144 accumulator registers reserved and spills the output
+    // stage, and a spill reload there waits for the stores in flight: vmcnt counts stores too).  The two
+    // groups run through separate code paths with the same three barriers ----
+#if B2F_WINO_TRACE
+    if (tr_on && lane == 0) tr_buf[152] = clock64();
+#endif
     float *X = reinterpret_cast<float *>(smem);
     float *ob = p.out + (size_t)img * p.out_img_stride;
-    const bool vec_ok = ((p.out_pix_stride | (int)p.out_chunk_stride) & 3) == 0;
-    const int o_jp = tid & 1, o_cq = (tid >> 1) & 7, o_t = tid >> 4;
-    const int o_xr = o_t ^ ((o_t >> 2) & 1);
-    const int oy = oy0 + 4 * (o_t >> 3), ox = ox0 + 4 * (o_t & 7);
-#pragma unroll 1
-    for (int pass = 0; pass < NTV; ++pass) {
-        if (n == pass) {
-#pragma unroll
-            for (int x = 0; x < 9; ++x)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = ((r & 3) + 8 * (r >> 2) + 4 * half) ^ half;
-                    X[((9 * g + x) * 32 + t) * 32 + m] = acc[x][r];
-                }
+#define W4_DUMP_ACC(tag_)                                                                           \
+    asm volatile("; accumulators of N tile %0 -> LDS" ::"n"(tag_));                                 \
+    _Pragma("unroll") for (int x = 0; x < 9; ++x)                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
+            const int t = ((r & 3) + 8 * (r >> 2) + 4 * half) ^ half;                               \
+            X[((9 * g + x) * 32 + t) * 32 + m] = acc[x][r];                                         \
         }
+    // W4_LDS_BARRIER: barrier that orders LDS traffic only.  __syncthreads() is also a release fence: after
+    // the output stage it would hold the barrier until every global store of the tile has been acknowledged
+    // (measured: ~25000 cycles per tile), although the next tile only needs the LDS reads to be over.
+#define W4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (n == 0) {
+        W4_DUMP_ACC(0);
         __syncthreads();
-        {
-            const int co0 = nb * 64 + pass * 32 + 4 * o_cq;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
-            // column pair jp = 0: output columns 0 and 2 (T0 = M0 + s1 + s2, T2 = s1 + 4 s2 with s = sums),
-            //             jp = 1: output columns 1 and 3 (T1 = d1 + 2 d2, T3 = d1 + 8 d2 + M5 with d = differences)
-            const float *xp = X + o_xr * 32 + 4 * o_cq + (o_jp ? 5 : 0) * 1024;   // jp = 1 reads M5 instead of M0
-            const float sg = o_jp ? -1.f : 1.f;
-            const f32x4 sg4 = {sg, sg, sg, sg};
-            const float ka = o_jp ? 2.f : 1.f, kb = o_jp ? 8.f : 4.f;
-            const f32x4 ka4 = {ka, ka, ka, ka}, kb4 = {kb, kb, kb, kb};
-            f32x4 Ta[6], Tb[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const float *xa = X + o_xr * 32 + 4 * o_cq + (6 * a) * 1024;
-                const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xa + 1 * 1024), m2 = *reinterpret_cast<const f32x4 *>(xa + 2 * 1024);
-                const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xa + 3 * 1024), m4 = *reinterpret_cast<const f32x4 *>(xa + 4 * 1024);
-                const f32x4 me = *reinterpret_cast<const f32x4 *>(xp + (6 * a) * 1024);   // M0 (jp 0) or M5 (jp 1)
-                const f32x4 e1 = W4_FMA(sg4, m2, m1), e2 = W4_FMA(sg4, m4, m3);           // sums or differences
-                // jp 0: Ta = M0 + s1 + s2, Tb = s1 + 4 s2;   jp 1: Ta = d1 + 2 d2, Tb = d1 + 8 d2 + M5
-                const f32x4 ta = W4_FMA(ka4, e2, e1), tb = W4_FMA(kb4, e2, e1);
-                Ta[a] = o_jp ? ta : ta + me;
-                Tb[a] = o_jp ? tb + me : tb;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 *Tq = q ? Tb : Ta;
-                const int j = o_jp + 2 * q;
-                const f32x4 s1 = Tq[1] + Tq[2], d1 = Tq[1] - Tq[2], s2 = Tq[3] + Tq[4], d2 = Tq[3] - Tq[4];
-                const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f};
-                f32x4 y[4];
-                y[0] = Tq[0] + s1 + s2;
-                y[1] = W4_FMA(k2, d2, d1);
-                y[2] = W4_FMA(k4, s2, s1);
-                y[3] = W4_FMA(k8, d2, d1) + Tq[5];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 v = y[i] + bias;
-                    if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
-                    if (oy + i < p.Ho && ox + j < p.Wo && co0 < p.cout) {
-                        float *dst = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co0 & 7);
-                        if (vec_ok && co0 + 3 < p.cout) {
-                            *reinterpret_cast<f32x4 *>(dst) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (co0 + e < p.cout)
-                                    ob[(size_t)((co0 + e) >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + ((co0 + e) & 7)] = v[e];
-                        }
-                    }
-                }
-            }
+        wino4_output_tile<0>(X, p, tid & 255, nb * 64, oy0, ox0, ob);
+        if (NTV == 2) {
+            W4_LDS_BARRIER();          // X free again
+            W4_LDS_BARRIER();          // accumulators of N tile 1 are in X
+            wino4_output_tile<1>(X, p, tid & 255, nb * 64 + 32, oy0, ox0, ob);
         }
+    } else if (NTV == 2) {
+        W4_LDS_BARRIER();
+        W4_LDS_BARRIER();
+        W4_DUMP_ACC(1);
+        W4_LDS_BARRIER();
+    } else {
         __syncthreads();
     }
+#undef W4_LDS_BARRIER
+#undef W4_DUMP_ACC
+#if B2F_WINO_TRACE
+    if (tr_on && lane == 0) tr_buf[153] = clock64();
+#endif
 }
 
 template <int NTV>
@@ -432,6 +454,8 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 for (int c = 0; c < 16; ++c)
                     fprintf(stderr, "  c=%2d  %7lld %7lld %7lld %7lld %7lld\n", c, t[c * 5] - t[0], t[c * 5 + 1] - t[0], t[c * 5 + 2] - t[0],
                             t[c * 5 + 3] - t[0], t[c * 5 + 4] - t[0]);
+                fprintf(stderr, "  kernel start %lld, loop start %lld, loop end %lld, pass 0 done %lld, pass 1 done %lld\n", t[150] - t[0],
+                        t[151] - t[0], t[152] - t[0], t[153] - t[0], t[154] - t[0]);
             }
     }
 #endif
@@ -442,6 +466,7 @@ bool wino4_supported(const ConvLaunch &p)
 {
     if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
     if (p.nseg > 1 && p.seg[1].pix_stride != p.seg[0].pix_stride) return false;
+    if (((p.out_pix_stride | (int)p.out_chunk_stride) & 3) != 0 || (p.cout & 3) != 0) return false;   // 16-byte stores
     return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 4294967296.0;   // 32-bit byte offsets inside a plane
 }
 
