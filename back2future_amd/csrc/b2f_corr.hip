@@ -82,22 +82,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// Profiling ablations are compile-time (-DB2F_CORR_ABLATE=bits: 1 no gather loads, 2 no FMAs, 4 no
-// stores, 8 no XCD remap): a runtime branch around the loads makes s_waitcnt insertion pessimistic.
-#ifndef B2F_CORR_ABLATE
-#define B2F_CORR_ABLATE 0
-#endif
 template <bool POW2>
 __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p)
 {
-    constexpr int ABL = B2F_CORR_ABLATE;
     __shared__ __attribute__((aligned(16))) float4 nb[2][2][HH * HP];   // [map][k4][pixel] 32 KB
     __shared__ float4 samp_w[2][NHALO];                                  // 12 KB
     __shared__ SampIdx samp_i[2][NHALO];                                 // 6 KB
 
     const int tid = threadIdx.x;
     const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
-    int bid = (ABL & 8) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    int bid = (p.ablate & 8) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
     const int ty_i = bid % tiles_y;
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
             const float *src = nbr[map] + coff + si.idx;
             const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
             float4 t[8];
-            if (!(ABL & 1)) {
+            if (!(p.ablate & 1)) {
 #pragma unroll
                 for (int k4 = 0; k4 < 2; ++k4) {
                     t[k4 * 4 + 0] = *reinterpret_cast<const float4 *>(src + 4 * k4);
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
         // 18 steps = 2 k4 x 9 qx columns; the 9 ds_read_b128 of step s+1 are issued before the
         // 36 FMAs of step s (two register sets), so LDS latency hides under the FMAs of the
         // same wave instead of relying on other waves.
-        if (!(ABL & 2)) {
+        if (!(p.ablate & 2)) {
             float4 va[9], vb[9];
 #pragma unroll
             for (int j = 0; j < 9; ++j) va[j] = myn[-(j - 4) * HP + 4];
@@ -224,7 +218,7 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
     }
 
     if (!pvalid) return;
-    if ((ABL & 4) && acc[0] != 12345.678f) return;   // profiling only: drop the stores, keep acc live
+    if ((p.ablate & 4) && acc[0] != 12345.678f) return;   // profiling only: drop the stores, keep acc live
     // ---- scale by 1/C (output:div(N), CostVolMulti.lua:100) and store the record slots ----
     const float cf = (float)p.C, inv = 1.f / cf;
 #pragma unroll
@@ -267,7 +261,9 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     if (p_in.C % 8 != 0 || p_in.pix_stride % 4 != 0 || p_in.chunk_stride % 4 != 0 || p_in.out_pix_stride % 4 != 0 ||
         p_in.out_chunk_stride % 4 != 0)
         return hipErrorInvalidValue;
-    const CorrLaunch &p = p_in;
+    static const int ablate = getenv("B2F_CORR_ABLATE") ? atoi(getenv("B2F_CORR_ABLATE")) : 0;
+    CorrLaunch p = p_in;
+    p.ablate = ablate;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * p.B));

@@ -89,6 +89,7 @@ struct CorrLaunch {
     long out_img_stride, out_chunk_stride;
     int out_pix_stride;
     int B, C, h, w;
+    int ablate;                              // profiling only (env B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
 };
 // slot of cost-volume channel c (0..80) of direction dir (0 fwd, 1 bwd) inside a record
 inline int cv_slot(int dir, int c) { return c < 80 ? dir * 80 + c : 160 + dir; }
