@@ -65,6 +65,9 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 #ifndef B2F_WINO_TRACE
 #define B2F_WINO_TRACE 0
 #endif
+#ifndef B2F_WINO4_SETPRIO
+#define B2F_WINO4_SETPRIO 0
+#endif
 #if B2F_WINO_TRACE
 #define W4_T(k_) do { if (tr_on && lane == 0 && c < 32) tr_buf[(c * 5 + (k_))] = clock64(); } while (0)
 #else
@@ -242,16 +245,37 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     // column pass: V[a][.] = R B, then the 6 b128 writes (waves 6, 7 masked)
 #define W4_T_COLS(vbuf_)                                                                            \
     do {                                                                                            \
-        const f32x4 k4v = {4.f, 4.f, 4.f, 4.f}, k5v = {-5.f, -5.f, -5.f, -5.f}, km4 = {-4.f, -4.f, -4.f, -4.f}; \
-        const f32x4 k2v = {2.f, 2.f, 2.f, 2.f}, km2 = {-2.f, -2.f, -2.f, -2.f};                     \
-        const f32x4 v0 = W4_FMA(k5v, R[2], W4_FMA(k4v, R[0], R[4]));                                \
-        const f32x4 pq = W4_FMA(km4, R[2], R[4]), qq = W4_FMA(km4, R[1], R[3]);                     \
-        const f32x4 uu = R[4] - R[2], vv = R[3] - R[1];                                             \
-        const f32x4 v5 = W4_FMA(k5v, R[3], W4_FMA(k4v, R[1], R[5]));                                \
+        const f32x2 k4v = {4.f, 4.f}, k5v = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2v = {2.f, 2.f}, km2 = {-2.f, -2.f}; \
+        f32x4 vo[6];                                                                                \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                          \
+            f32x2 r0 = hh ? __builtin_shufflevector(R[0], R[0], 2, 3) : __builtin_shufflevector(R[0], R[0], 0, 1); \
+            f32x2 r1 = hh ? __builtin_shufflevector(R[1], R[1], 2, 3) : __builtin_shufflevector(R[1], R[1], 0, 1); \
+            f32x2 r2 = hh ? __builtin_shufflevector(R[2], R[2], 2, 3) : __builtin_shufflevector(R[2], R[2], 0, 1); \
+            f32x2 r3 = hh ? __builtin_shufflevector(R[3], R[3], 2, 3) : __builtin_shufflevector(R[3], R[3], 0, 1); \
+            f32x2 r4 = hh ? __builtin_shufflevector(R[4], R[4], 2, 3) : __builtin_shufflevector(R[4], R[4], 0, 1); \
+            f32x2 r5 = hh ? __builtin_shufflevector(R[5], R[5], 2, 3) : __builtin_shufflevector(R[5], R[5], 0, 1); \
+            f32x2 t0, t1, pq, qq, uu, vv, o1, o2, o3, o4;                                           \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "s"(k4v), "v"(r0), "v"(r4));    \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t0) : "s"(k5v), "v"(r2));             \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pq) : "s"(km4), "v"(r2), "v"(r4));    \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(qq) : "s"(km4), "v"(r1), "v"(r3));    \
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(uu) : "v"(r4), "v"(r2)); \
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(vv) : "v"(r3), "v"(r1)); \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "s"(k4v), "v"(r1), "v"(r5));    \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t1) : "s"(k5v), "v"(r3));             \
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o1) : "v"(pq), "v"(qq));                  \
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o2) : "v"(pq), "v"(qq)); \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o3) : "s"(k2v), "v"(vv), "v"(uu));    \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o4) : "s"(km2), "v"(vv), "v"(uu));    \
+            if (hh == 0) {                                                                          \
+                vo[0].xy = t0; vo[1].xy = o1; vo[2].xy = o2; vo[3].xy = o3; vo[4].xy = o4; vo[5].xy = t1; \
+            } else {                                                                                \
+                vo[0].zw = t0; vo[1].zw = o1; vo[2].zw = o2; vo[3].zw = o3; vo[4].zw = o4; vo[5].zw = t1; \
+            }                                                                                       \
+        }                                                                                           \
         if (t_write) {                                                                              \
             f32x4 *v = Vb + (vbuf_) * V_F4 + t_dst;                                                 \
-            v[0] = v0; v[64] = pq + qq; v[128] = pq - qq;                                           \
-            v[192] = W4_FMA(k2v, vv, uu); v[256] = W4_FMA(km2, vv, uu); v[320] = v5;                \
+            _Pragma("unroll") for (int b = 0; b < 6; ++b) v[64 * b] = vo[b];                        \
         }                                                                                           \
     } while (0)
 
@@ -329,9 +353,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             if (x == 8) av[1] = Vn[64];
             __builtin_amdgcn_sched_barrier(0);
             if (NTV == 2 || mf_on) {
+#if B2F_WINO4_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[x % 3][j], acc[x], 0, 0, 0);
+#if B2F_WINO4_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if (x < 6) {
