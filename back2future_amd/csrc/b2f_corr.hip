@@ -75,13 +75,6 @@ __device__ __forceinline__ void top_left(float coord, int size, int &pt, float &
 // with the natural order the 3x halo overlap of neighbouring tiles is re-fetched from the fabric
 // by up to 8 different L2s.  Give every XCD one contiguous band of tiles instead (bijective for
 // any grid size; placement only affects speed, never results).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg)
-{
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 template <bool POW2>
 __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p)
 {

@@ -284,6 +284,96 @@ hipError_t launch_conv_first(const float *in, int normalize, int B, int H, int W
     return hipGetLastError();
 }
 
+// nn.SpatialConvolution(Ci, 2, 3,3,1,1,1,1) -- the last layer of every decoder (pwc.lua:82, 2 outputs: flow
+// (u, v) resp. the two occlusion logits) -- as a plain VALU kernel: with 2 outputs an MFMA tile would be 94 %
+// padding.  HBM-bound (Ci * 4 B read per pixel).  Block = 256 threads = 16 x 16 pixels; the 18 x 18 patch of up
+// to 32 input channels sits in LDS as [chunk][k4][pixel] float4 (conflict-free b128 reads); weights
+// [chunk][tap][8 ci][2 co] come in as scalar (SGPR) operands; one thread = one pixel, 2 x 9 x Ci fmas.
+// Chunk-planar in, chunk-planar out (channels 0, 1 of output chunk 0).
+__global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long img_stride, long chunk_stride, int pix_stride,
+                                                           int nchunks, int H, int W, const float *wt, const float *bias,
+                                                           float *out, long out_img_stride, int out_pix_stride, int leaky)
+{
+    constexpr int T = 16, P = T + 2, NP = P * P;     // 324 patch pixels
+    __shared__ float4 patch[4][2][NP + 4];
+    const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int ox0 = tx_i * T, oy0 = ty_i * T;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const float *src = in + (size_t)img * img_stride;
+    float a0 = bias[0], a1 = bias[1];
+    for (int c0 = 0; c0 < nchunks; c0 += 4) {
+        const int nc = min(4, nchunks - c0);
+        if (c0) __syncthreads();
+        for (int i = threadIdx.x; i < nc * 2 * NP; i += 256) {
+            const int c = i / (2 * NP), r = i - c * (2 * NP);
+            const int pix = r >> 1, k4 = r & 1;
+            const int py = pix / P, px = pix - py * P;
+            const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(src + (size_t)(c0 + c) * chunk_stride + ((size_t)gy * W + gx) * pix_stride + 4 * k4);
+            patch[c][k4][pix] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            const float *w = wt + (size_t)(c0 + c) * (9 * 8 * 2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int pp = (ty + ky) * P + tx + kx;
+                    const float4 lo = patch[c][0][pp], hi = patch[c][1][pp];
+                    const float *wk = w + (ky * 3 + kx) * 16;
+                    a0 = fmaf(lo.x, wk[0], a0);  a1 = fmaf(lo.x, wk[1], a1);
+                    a0 = fmaf(lo.y, wk[2], a0);  a1 = fmaf(lo.y, wk[3], a1);
+                    a0 = fmaf(lo.z, wk[4], a0);  a1 = fmaf(lo.z, wk[5], a1);
+                    a0 = fmaf(lo.w, wk[6], a0);  a1 = fmaf(lo.w, wk[7], a1);
+                    a0 = fmaf(hi.x, wk[8], a0);  a1 = fmaf(hi.x, wk[9], a1);
+                    a0 = fmaf(hi.y, wk[10], a0); a1 = fmaf(hi.y, wk[11], a1);
+                    a0 = fmaf(hi.z, wk[12], a0); a1 = fmaf(hi.z, wk[13], a1);
+                    a0 = fmaf(hi.w, wk[14], a0); a1 = fmaf(hi.w, wk[15], a1);
+                }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= H || ox >= W) return;
+    if (leaky) { a0 = a0 > 0.f ? a0 : 0.2f * a0; a1 = a1 > 0.f ? a1 : 0.2f * a1; }
+    float *op = out + (size_t)img * out_img_stride + ((size_t)oy * W + ox) * out_pix_stride;
+    *reinterpret_cast<float2 *>(op) = make_float2(a0, a1);
+}
+
+hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s)
+{
+    if (p.stride != 1 || p.cout != 2 || p.nseg != 1 || (p.seg[0].pix_stride & 3) || (p.out_pix_stride & 1)) return hipErrorInvalidValue;
+    const int tiles = ((p.W + 15) / 16) * ((p.H + 15) / 16);
+    hipLaunchKernelGGL(conv_narrow2_kernel, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p.seg[0].ptr, p.seg[0].img_stride,
+                       p.seg[0].chunk_stride, p.seg[0].pix_stride, p.seg[0].nchunks, p.H, p.W, p.wpk, p.bias, p.out,
+                       p.out_img_stride, p.out_pix_stride, p.leaky);
+    return hipGetLastError();
+}
+
+size_t narrow2_wpk_floats(int cin_chunks) { return (size_t)cin_chunks * 9 * 8 * 2; }
+
+// [chunk][tap][8 ci][2 co]; channels missing from cin_map (padding) get zero weights
+void narrow2_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk)
+{
+    for (int c = 0; c < cin_chunks; ++c)
+        for (int t = 0; t < 9; ++t)
+            for (int j = 0; j < 8; ++j)
+                for (int o = 0; o < 2; ++o) {
+                    const int k = c * kCK + j;
+                    const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
+                    wpk[((c * 9 + t) * 8 + j) * 2 + o] = ci >= 0 ? w[((size_t)o * Ci + ci) * 9 + t] : 0.f;
+                }
+    bpk[0] = b[0];
+    bpk[1] = b[1];
+}
+
 // ---- iws[1][3] for Hard models straight from the planar API tensor: frame `frame` of in
 // (B x 9 x H x W), normalized on the fly, warped by k * planar flow -> planar B x 3 x H x W ----
 __global__ void warp_input_planar_kernel(const float *in, int normalize, int frame, const float *flow, float k, int B,

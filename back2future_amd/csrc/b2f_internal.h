@@ -62,6 +62,10 @@ void conv_choose_tiles(int cout, int *nt, int *nblk);
 void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
                        int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
 
+// ---- 2-output stride-1 layers (last decoder layer): VALU kernel in b2f_glue.hip, weights [chunk][tap][8][2]
+hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s);
+size_t narrow2_wpk_floats(int cin_chunks);
+void narrow2_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // ---- Winograd F(2x2,3x3) variant for stride-1 layers (b2f_wino.hip); same ConvLaunch, weights
 // packed by wino_pack_weights ([nblk][chunk][xi 16][k4 2][NT*32][4]), nt in {1, 2}
 hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s);
@@ -91,6 +95,17 @@ struct CorrLaunch {
     int B, C, h, w;
     int ablate;                              // profiling only (env B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
 };
+#ifdef __HIPCC__
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one
+// contiguous range of logical work items instead (bijective for any grid size; placement only affects speed).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+#endif
+
 // slot of cost-volume channel c (0..80) of direction dir (0 fwd, 1 bwd) inside a record
 inline int cv_slot(int dir, int c) { return c < 80 ? dir * 80 + c : 160 + dir; }
 hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);

@@ -98,12 +98,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m = lane & 31, half = lane >> 5;
 
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-    int bid = blockIdx.x;
+    // 1-D grid, logical index = (image, tile row, tile column, n-block) with the n-block fastest, remapped so
+    // that each XCD walks a contiguous range: the n-blocks of a tile and neighbouring tiles (which share the
+    // raw patch resp. its halo) run on the same XCD at about the same time and find each other's lines in L2
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid % p.nblk + p.nb0;
+    bid /= p.nblk;
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
     const int ty_i = bid % tiles_y;
     const int img = bid / tiles_y;
-    const int nb = blockIdx.y + p.nb0;
     const int ox0 = tx_i * TW, oy0 = ty_i * TH;
     const int ix0 = ox0 - 1, iy0 = oy0 - 1;
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #if B2F_WINO_TRACE
     const int tr_slot = blockIdx.x == 1000 ? 0 : blockIdx.x == 1001 ? 1 : blockIdx.x == 5000 ? 2 : blockIdx.x == 5256 ? 3 : -1;
-    const bool tr_on = p.trace && tr_slot >= 0 && blockIdx.y == 0;
+    const bool tr_on = p.trace && tr_slot >= 0;
     long long *tr_buf = p.trace + (tr_on ? (tr_slot * 4 + wave) * 160 : 0);
 #endif
     for (int c = 0; c < nchunks; ++c) {
@@ -358,7 +362,8 @@ static hipError_t launch_wino_t(const ConvLaunch &p, int nb0, int nblk, hipStrea
     }
 #endif
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
-    dim3 grid((unsigned)(tiles * p.nimg), (unsigned)nblk);
+    q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
+    dim3 grid((unsigned)(tiles * p.nimg * nblk));
     hipLaunchKernelGGL((conv3x3_wino<NT, NTV>), grid, dim3(256), lds, s, q);
 #if B2F_WINO_TRACE
     if (do_trace) {

@@ -68,6 +68,11 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 #ifndef B2F_WINO4_SETPRIO
 #define B2F_WINO4_SETPRIO 0
 #endif
+// Profiling only (results are wrong): -DB2F_WINO4_ABLATE=bits, 1 no input transform, 2 no raw staging, 4 no B loads,
+// 8 no MFMAs, 16 no A operand reads
+#ifndef B2F_WINO4_ABLATE
+#define B2F_WINO4_ABLATE 0
+#endif
 #if B2F_WINO_TRACE
 #define W4_T(k_) do { if (tr_on && lane == 0 && c < 32) tr_buf[(c * 5 + (k_))] = clock64(); } while (0)
 #else
@@ -142,12 +147,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const int g = wave & 3, n = wave >> 2;
 
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-    int bid = blockIdx.x;
+    // 1-D grid, logical index = (image, tile row, tile column, n-block) with the n-block fastest, remapped so
+    // that each XCD walks a contiguous range: the n-blocks of a tile and neighbouring tiles (which share the
+    // raw patch resp. its halo) run on the same XCD at about the same time and find each other's lines in L2
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid % p.nblk + p.nb0;
+    bid /= p.nblk;
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
     const int ty_i = bid % tiles_y;
     const int img = bid / tiles_y;
-    const int nb = blockIdx.y + p.nb0;
     const int ox0 = tx_i * TW, oy0 = ty_i * TH;
     const int ix0 = ox0 - 1, iy0 = oy0 - 1;
 
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 
 #if B2F_WINO_TRACE
     const int tr_slot = blockIdx.x == 300 ? 0 : blockIdx.x == 301 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1456 ? 3 : -1;
-    const bool tr_on = p.trace && tr_slot >= 0 && blockIdx.y == 0;
+    const bool tr_on = p.trace && tr_slot >= 0;
     long long *tr_buf = p.trace + (tr_on ? (tr_slot * 8 + wave) * 160 : 0);
 #endif
 #if B2F_WINO_TRACE
@@ -341,18 +350,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         for (int x = 0; x < 9; ++x) {
             // B operand two xi ahead (next chunk's for x >= 7); A operand one xi ahead (xi 8 two ahead, so that
             // every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it)
-            if (NTV == 2 || mf_on) {
+            if (!(B2F_WINO4_ABLATE & 4) && (NTV == 2 || mf_on)) {
                 if (x + 2 < 9) W4_LOAD_U((x + 2) % 3, c, x + 2);
                 else if (x == 8) W4_LOAD_U(1, cn, 1);
                 // (the load of xi 0 of the next chunk, due at x == 7, is issued at the end of step 6, ahead of the
                 // raw loads: s_waitcnt vmcnt is in order, every B operand fetched after them waits for HBM)
             }
-            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];
-            if (x == 6) av[8 % 3] = Vc[8 * 64];
-            if (x == 7) av[0] = Vn[0];
-            if (x == 8) av[1] = Vn[64];
+            if (!(B2F_WINO4_ABLATE & 16)) {
+                if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];
+                if (x == 6) av[8 % 3] = Vc[8 * 64];
+                if (x == 7) av[0] = Vn[0];
+                if (x == 8) av[1] = Vn[64];
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (NTV == 2 || mf_on) {
+            if (!(B2F_WINO4_ABLATE & 8) && (NTV == 2 || mf_on)) {
 #if B2F_WINO4_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -366,24 +377,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             __builtin_amdgcn_sched_barrier(0);
             if (x < 6) {
                 // slice x + 2 of Tr(c+1) (its reads were issued one step ago), then the reads of the next slice
-                W4_T_FMA(x + 2);
-                if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);
+                if (!(B2F_WINO4_ABLATE & 1)) {
+                    W4_T_FMA(x + 2);
+                    if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);
+                }
             } else if (x == 6) {
-                W4_T_COLS((c + 1) & 1);
-                W4_WRITE_RAW(c & 1);
-                if (NTV == 2 || mf_on) W4_LOAD_U(0, cn, 0);
+                if (!(B2F_WINO4_ABLATE & 1)) W4_T_COLS((c + 1) & 1);
+                if (!(B2F_WINO4_ABLATE & 2)) W4_WRITE_RAW(c & 1);
+                if (!(B2F_WINO4_ABLATE & 4) && (NTV == 2 || mf_on)) W4_LOAD_U(0, cn, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 W4_T(3);
                 __syncthreads();
                 W4_T(4);
-                W4_T_READ(0, c & 1);                       // Tr(c+2), raw(c+2) is in raw buffer c & 1
-                W4_LOAD_RAW(min(c + 3, nchunks - 1));
+                if (!(B2F_WINO4_ABLATE & 1)) W4_T_READ(0, c & 1);   // Tr(c+2), raw(c+2) is in raw buffer c & 1
+                if (!(B2F_WINO4_ABLATE & 2)) W4_LOAD_RAW(min(c + 3, nchunks - 1));
             } else if (x == 7) {
-                W4_T_FMA(0);
-                W4_T_READ(1, c & 1);
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(0); W4_T_READ(1, c & 1); }
             } else {
-                W4_T_FMA(1);
-                W4_T_READ(2, c & 1);
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(1); W4_T_READ(2, c & 1); }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (x == 2) W4_T(1);
@@ -469,7 +480,8 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     }
 #endif
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
-    dim3 grid((unsigned)(tiles * p.nimg), (unsigned)nblk);
+    q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
+    dim3 grid((unsigned)(tiles * p.nimg * nblk));
     hipLaunchKernelGGL((conv3x3_wino4<NTV>), grid, dim3(512), LDS_BYTES, s, q);
 #if B2F_WINO_TRACE
     if (do_trace) {
