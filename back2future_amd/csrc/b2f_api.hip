@@ -44,6 +44,10 @@ struct PackedConv {
     int cout = 0, nt = 1, nblk = 1;
     int wino = 0;                  // 0 direct kernel, 1 VALU kernel for 2 outputs, 2 Winograd F(2x2,3x3), 4 Winograd F(4x4,3x3)
     size_t w_off = 0, b_off = 0;   // float offsets into wpk_dev
+    // F(4x4) layers also carry an F(2x2) packing for small maps (one 16 x 32-pixel block per CU does not fill
+    // the chip below ~64 x 64 pixels; measured at 32 x 60: 0.05 ms vs 0.14 ms)
+    int nt2 = 0, nblk2 = 0;
+    size_t w_off2 = 0, b_off2 = 0;
 };
 
 struct ProfEvent {
@@ -231,6 +235,13 @@ int pack_all(b2f_ctx *c, const float *flat)
                  : p.wino == 2 ? wino_wpk_floats(chunks, p.nt, p.nblk) : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
+        if (p.wino == 4) {
+            wino_choose_tiles(d.co, &p.nt2, &p.nblk2);
+            p.w_off2 = total;
+            total += wino_wpk_floats(chunks, p.nt2, p.nblk2);
+            p.b_off2 = total;
+            total += (size_t)p.nblk2 * p.nt2 * 32;
+        }
     }
     c->first_w_off = total; total += 27 * 16;
     c->first_b_off = total; total += 16;
@@ -247,10 +258,12 @@ int pack_all(b2f_ctx *c, const float *flat)
         const ConvDesc &d = c->lay[i];
         const PackedConv &p = c->packed[i];
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
-        if (p.wino == 4)
+        if (p.wino == 4) {
             wino4_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nblk,
                                host.data() + p.w_off, host.data() + p.b_off);
-        else if (p.wino == 1)
+            wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt2, p.nblk2,
+                              host.data() + p.w_off2, host.data() + p.b_off2);
+        } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
                                  host.data() + p.b_off);
         else if (p.wino == 2)
@@ -349,6 +362,11 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
              int stride, int leaky, float *out)
 {
     const PackedConv &p = c->packed[conv_id];
+    // kernel for this call: F(4x4) layers fall back to their F(2x2) packing on small maps
+    static const int small_px = getenv("B2F_WINO4_MIN_PIXELS") ? atoi(getenv("B2F_WINO4_MIN_PIXELS")) : 4096;
+    const bool alt = p.wino == 4 && H * W < small_px;
+    const int mode = alt ? 2 : p.wino;
+    const int nt = alt ? p.nt2 : p.nt, nblk = alt ? p.nblk2 : p.nblk;
     ConvLaunch L;
     L.nseg = p.nseg;
     for (int i = 0; i < p.nseg; ++i) {
@@ -356,12 +374,12 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
         L.seg[i].nchunks = p.chunks[i];
     }
     if (p.nseg == 1) L.seg[1] = L.seg[0], L.seg[1].nchunks = 0;
-    L.wpk = c->wpk_dev + p.w_off;
-    L.bias = c->wpk_dev + p.b_off;
+    L.wpk = c->wpk_dev + (alt ? p.w_off2 : p.w_off);
+    L.bias = c->wpk_dev + (alt ? p.b_off2 : p.b_off);
     L.out = out;
     L.cout = p.cout;
-    L.nt = p.nt;
-    L.nblk = p.nblk;
+    L.nt = nt;
+    L.nblk = nblk;
     L.H = H; L.W = W; L.stride = stride;
     L.Ho = (H + 2 - 3) / stride + 1;
     L.Wo = (W + 2 - 3) / stride + 1;
@@ -373,15 +391,15 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     char name[48];
     static const bool per_layer = getenv("B2F_PROFILE_LAYERS") != nullptr;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", p.wino == 4 ? "W4" : p.wino == 2 ? "W2" : p.wino == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, p.wino == 4 ? "conv3x3_wino4_nt%d" : p.wino == 2 ? "conv3x3_wino_nt%d" : p.wino == 1 ? "conv3x3_narrow%d"
-                                    : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), p.wino == 1 ? 2 : p.nt);
+        snprintf(name, sizeof name, mode == 4 ? "conv3x3_wino4_nt%d" : mode == 2 ? "conv3x3_wino_nt%d" : mode == 1 ? "conv3x3_narrow%d"
+                                    : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"), mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
-    if (p.wino == 4) HIPCHK(launch_conv3x3_wino4(L, s));
-    else if (p.wino == 1) HIPCHK(launch_conv_narrow2(L, s));
-    else if (p.wino == 2) HIPCHK(launch_conv3x3_wino(L, s));
+    if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
+    else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
+    else if (mode == 2) HIPCHK(launch_conv3x3_wino(L, s));
     else HIPCHK(launch_conv3x3(L, s));
     return 0;
 }
