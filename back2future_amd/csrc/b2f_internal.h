@@ -62,6 +62,11 @@ void conv_choose_tiles(int cout, int *nt, int *nblk);
 void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
                        int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
 
+// ---- 16 -> 16 stride-1 layer (level-2 convUnit): single-pass kernel on the 16x16x4 MFMA (b2f_conv16.hip),
+// weights [tap 9][kg 4][co 16][4]
+hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s);
+size_t c16_wpk_floats();
+void c16_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, float *wpk, float *bpk);
 // ---- 2-output stride-1 layers (last decoder layer): VALU kernel in b2f_glue.hip, weights [chunk][tap][8][2]
 hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s);
 size_t narrow2_wpk_floats(int cin_chunks);
