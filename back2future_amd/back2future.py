@@ -45,7 +45,8 @@ class Model(object):
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().b2f_destroy(self._h)
+            if _lib is not None:            # None while the interpreter tears the module down
+                _lib.lib().b2f_destroy(self._h)
             self._h = None
 
     __del__ = close

@@ -431,23 +431,36 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     // the output stage it would hold the barrier until every global store of the tile has been acknowledged
     // (measured: ~25000 cycles per tile), although the next tile only needs the LDS reads to be over.
 #define W4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#if B2F_WINO_TRACE
+#define W4_E(k_) do { if (tr_on && lane == 0) tr_buf[140 + (k_)] = clock64(); } while (0)
+#else
+#define W4_E(k_) do {} while (0)
+#endif
     if (n == 0) {
         W4_DUMP_ACC(0);
+        W4_E(0);
         __syncthreads();
+        W4_E(1);
         wino4_output_tile<0>(X, p, tid & 255, nb * 64, oy0, ox0, ob);
+        W4_E(2);
         if (NTV == 2) {
             W4_LDS_BARRIER();          // X free again
             W4_LDS_BARRIER();          // accumulators of N tile 1 are in X
+            W4_E(3);
             wino4_output_tile<1>(X, p, tid & 255, nb * 64 + 32, oy0, ox0, ob);
+            W4_E(4);
         }
     } else if (NTV == 2) {
         W4_LDS_BARRIER();
         W4_LDS_BARRIER();
+        W4_E(0);
         W4_DUMP_ACC(1);
+        W4_E(1);
         W4_LDS_BARRIER();
     } else {
         __syncthreads();
     }
+#undef W4_E
 #undef W4_LDS_BARRIER
 #undef W4_DUMP_ACC
 #if B2F_WINO_TRACE
@@ -496,8 +509,8 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 for (int c = 0; c < 16; ++c)
                     fprintf(stderr, "  c=%2d  %7lld %7lld %7lld %7lld %7lld\n", c, t[c * 5] - t[0], t[c * 5 + 1] - t[0], t[c * 5 + 2] - t[0],
                             t[c * 5 + 3] - t[0], t[c * 5 + 4] - t[0]);
-                fprintf(stderr, "  kernel start %lld, loop start %lld, loop end %lld, pass 0 done %lld, pass 1 done %lld\n", t[150] - t[0],
-                        t[151] - t[0], t[152] - t[0], t[153] - t[0], t[154] - t[0]);
+                fprintf(stderr, "  kernel start %lld, loop start %lld, loop end %lld, end %lld | epilogue stamps %lld %lld %lld %lld %lld\n", t[150] - t[0],
+                        t[151] - t[0], t[152] - t[0], t[153] - t[0], t[140] - t[0], t[141] - t[0], t[142] - t[0], t[143] - t[0], t[144] - t[0]);
             }
     }
 #endif
