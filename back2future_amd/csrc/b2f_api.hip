@@ -172,11 +172,11 @@ bool use_wino()
     return on;
 }
 
-// Kernel choice for a stride-1 layer: F(4x4) for the wide layers (>= B2F_WINO4_MIN_COUT outputs,
-// default 64; 0 disables it), F(2x2) down to 16 outputs, direct kernel below.
+// Kernel choice for a stride-1 layer: F(4x4) from B2F_WINO4_MIN_COUT outputs (default 32; 0 disables it),
+// F(2x2) down to B2F_WINO_MIN_COUT (default 16), direct kernel below; 2 outputs: VALU kernel.
 int wino_mode(int cout)
 {
-    static const int min4 = getenv("B2F_WINO4_MIN_COUT") ? atoi(getenv("B2F_WINO4_MIN_COUT")) : 64;
+    static const int min4 = getenv("B2F_WINO4_MIN_COUT") ? atoi(getenv("B2F_WINO4_MIN_COUT")) : 32;
     if (use_wino() && cout == 2) return 1;           // last decoder layer: VALU kernel
     static const int min2 = getenv("B2F_WINO_MIN_COUT") ? atoi(getenv("B2F_WINO_MIN_COUT")) : 16;
     if (!use_wino() || cout < min2) return 0;

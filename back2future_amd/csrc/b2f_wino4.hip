@@ -129,6 +129,57 @@ __device__ __forceinline__ void wino4_output_tile(const float *X, const ConvLaun
     }
 }
 
+// Half of the output stage of one N tile: item = (tile, 4 channels), output columns jp and jp + 2 only (the even
+// columns need only the sums M1+M2, M3+M4 of a row, the odd ones only the differences), eight 16-byte stores.
+// Used when all eight waves share one N tile (single-N-tile blocks).
+__device__ __forceinline__ void wino4_output_half(const float *X, const ConvLaunch &p, int idx, int o_jp, int co_base, int oy0, int ox0,
+                                                  float *ob)
+{
+    const int o_t = idx >> 3, o_cq = idx & 7;
+    const int xr = o_t ^ ((o_t >> 2) & 1);
+    const int co0 = co_base + 4 * o_cq;
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+    const float *xa = X + xr * 32 + 4 * o_cq;
+    const float *xe = xa + (o_jp ? 5 : 0) * 1024;            // M5 for the odd columns, M0 for the even ones
+    const float sg = o_jp ? -1.f : 1.f;
+    const f32x4 sg4 = {sg, sg, sg, sg};
+    const int oy = oy0 + 4 * (o_t >> 3), ox = ox0 + 4 * (o_t & 7);
+    float *obase = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox + o_jp) * p.out_pix_stride + (co0 & 7);
+    const bool col_ok = co0 < p.cout;
+    const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        // column j = jp + 2q of T = M A:  j=0: M0 + s1 + s2,  j=1: d1 + 2 d2,  j=2: s1 + 4 s2,  j=3: d1 + 8 d2 + M5
+        const float kq = q ? (o_jp ? 8.f : 4.f) : (o_jp ? 2.f : 1.f);
+        const float ke = (q == 0) == (o_jp == 0) ? 1.f : 0.f;          // add M0 (j = 0) or M5 (j = 3)
+        const f32x4 kq4 = {kq, kq, kq, kq}, ke4 = {ke, ke, ke, ke};
+        f32x4 T[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const float *xr6 = xa + (6 * a) * 1024;
+            const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xr6 + 1 * 1024), m2 = *reinterpret_cast<const f32x4 *>(xr6 + 2 * 1024);
+            const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xr6 + 3 * 1024), m4 = *reinterpret_cast<const f32x4 *>(xr6 + 4 * 1024);
+            const f32x4 me = *reinterpret_cast<const f32x4 *>(xe + (6 * a) * 1024);
+            const f32x4 e1 = W4_FMA(sg4, m2, m1), e2 = W4_FMA(sg4, m4, m3);   // sums (even j) or differences (odd j)
+            T[a] = W4_FMA(ke4, me, W4_FMA(kq4, e2, e1));
+        }
+        const f32x4 s1 = T[1] + T[2], d1 = T[1] - T[2], s2 = T[3] + T[4], d2 = T[3] - T[4];
+        f32x4 y[4];
+        y[0] = T[0] + s1 + s2;
+        y[1] = W4_FMA(k2, d2, d1);
+        y[2] = W4_FMA(k4, s2, s1);
+        y[3] = W4_FMA(k8, d2, d1) + T[5];
+        const int j = o_jp + 2 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = y[i] + bias;
+            if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
+            if (col_ok && oy + i < p.Ho && ox + j < p.Wo)
+                *reinterpret_cast<f32x4 *>(obase + (size_t)(i * p.Wo + 2 * q) * p.out_pix_stride) = v;
+        }
+    }
+}
+
 template <int NTV>
 __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 {
@@ -222,24 +273,26 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const float t_cf[4] = {c0, c1, c2, c3};     // wave-uniform (SGPRs)
     const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;        // float4 index of V[xi = 6a][k4][t]; xi+1 -> +64
     const bool t_write = wave < 6;
-    f32x4 R[6], d[3];
+    f32x4 R[6], d[NTV == 1 ? 6 : 3];
     // slice s = 2 r + h: input row r (of the four), columns 3h .. 3h+2 of the 6-wide tile window
-#define W4_T_READ(s_, rbuf_)                                                                        \
+#define W4_T_READ(s_, rbuf_) W4_T_READ_D(s_, rbuf_, 0)
+#define W4_T_READ_D(s_, rbuf_, db_)                                                                 \
     do {                                                                                            \
         const f32x4 *rp = Rb + (rbuf_) * RAW_F4 + t_row[(s_) >> 1];                                 \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) d[k] = rp[colpos(3 * ((s_) & 1) + k)];       \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) d[(db_) + k] = rp[colpos(3 * ((s_) & 1) + k)]; \
     } while (0)
     // Written as v_pk_* inline asm: hipcc unpacks packed fp32 ops that follow an MFMA into two scalar ones (it
     // assumes they co-issue with the MFMA; behind an fp32 MFMA they do not), and VALU instructions are what
     // this loop pays for.  The asm also pins the slice here (otherwise instruction selection sinks the fmas to
     // the column pass and all 24 raw float4 stay live).
-#define W4_T_FMA(s_)                                                                                \
+#define W4_T_FMA(s_) W4_T_FMA_D(s_, 0)
+#define W4_T_FMA_D(s_, db_)                                                                         \
     do {                                                                                            \
         const float cf = t_cf[(s_) >> 1];                                                           \
         const f32x2 cf2 = {cf, cf};                                                                 \
         _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                             \
             f32x4 &Rk = R[3 * ((s_) & 1) + k];                                                      \
-            const f32x2 dlo = __builtin_shufflevector(d[k], d[k], 0, 1), dhi = __builtin_shufflevector(d[k], d[k], 2, 3); \
+            const f32x2 dlo = __builtin_shufflevector(d[(db_) + k], d[(db_) + k], 0, 1), dhi = __builtin_shufflevector(d[(db_) + k], d[(db_) + k], 2, 3); \
             f32x2 lo = __builtin_shufflevector(Rk, Rk, 0, 1), hi = __builtin_shufflevector(Rk, Rk, 2, 3); \
             if (((s_) >> 1) == 0) {                                                                 \
                 asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "s"(cf2), "v"(dlo));            \
@@ -288,6 +341,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         }                                                                                           \
     } while (0)
 
+    if constexpr (NTV == 2) {
     f32x16 acc[9];
 #pragma unroll
     for (int x = 0; x < 9; ++x)
@@ -401,12 +455,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             if (x == 5) W4_T(2);
         }
     }
-#undef W4_LOAD_RAW
-#undef W4_WRITE_RAW
-#undef W4_T_READ
-#undef W4_T_FMA
-#undef W4_T_COLS
-#undef W4_LOAD_U
 
     // ---- output, one N tile at a time (LDS holds the 36 planes of 32 channels: 144 KB): the four waves of
     // the tile write their accumulators to X[xi][tile row][co 32] (tile rows t and t ^ 1 swapped when bit 2
@@ -463,6 +511,91 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #undef W4_E
 #undef W4_LDS_BARRIER
 #undef W4_DUMP_ACC
+    } else {
+    // =====================================================================================================
+    // Single N tile (NTV == 1: the last n-block of a layer whose cout is 32 mod 64): the 36 xi are split over
+    // ALL eight waves, wave (g, n) takes xi(x) = 9g + 5n + x, x = 0..4 (the fifth step of the n = 1 waves is a
+    // duplicate that is never dumped), so every wave keeps multiplying -- with one N tile per wave pair half of
+    // the waves had no MFMA work at all.  Only 5 accumulators: registers are plentiful, so the pipeline is the
+    // simple one (B operands a whole chunk ahead, A operands read after the barrier, two transform slices per
+    // xi step, one barrier at the end of the chunk).
+    // =====================================================================================================
+    f32x16 acc[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    int xo[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) xo[x] = min(9 * g + 5 * n + x, 35);
+    const int a_lane = half * 32 + m;                       // V[xi][k4 = half][tile m] = xi * 64 + a_lane (float4)
+    const unsigned b_lane = (half * 64 + m) * 16u;          // bytes: U[xi][k4 = half][co m] = xi * 2048 + b_lane
+    f32x4 av[5], bc[5], bn[5];
+#define W4S_LOAD_U(dst_, c_)                                                                        \
+    _Pragma("unroll") for (int x = 0; x < 5; ++x)                                                   \
+        dst_[x] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)(c_) * (U_F4 * 16) + b_lane + xo[x] * 2048)
+    {
+        f32x4 keep[3];
+        W4_LOAD_RAW(min(1, nchunks - 1));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep[i] = sr[i];
+        W4_LOAD_RAW(0);
+        W4S_LOAD_U(bc, 0);
+        W4_WRITE_RAW(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sr[i] = keep[i];
+        W4_WRITE_RAW(1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2); }
+    W4_T_COLS(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = min(c + 1, nchunks - 1);
+        W4S_LOAD_U(bn, cn);
+        W4_LOAD_RAW(min(c + 2, nchunks - 1));
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_lane;
+#pragma unroll
+        for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            if (x < 4) { W4_T_READ_D(2 * x, (c + 1) & 1, 0); W4_T_READ_D(2 * x + 1, (c + 1) & 1, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (x < 4) { W4_T_FMA_D(2 * x, 0); W4_T_FMA_D(2 * x + 1, 3); }
+            else { W4_T_COLS((c + 1) & 1); W4_WRITE_RAW(c & 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 5; ++x) bc[x] = bn[x];
+    }
+#undef W4S_LOAD_U
+    // output: all eight waves dump their xi planes, then every thread takes one half item
+    {
+        float *X = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+            if (x < 4 || n == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = ((r & 3) + 8 * (r >> 2) + 4 * half) ^ half;
+                    X[(xo[x] * 32 + t) * 32 + m] = acc[x][r];
+                }
+            }
+        __syncthreads();
+        wino4_output_half(X, p, tid & 255, tid >> 8, nb * 64, oy0, ox0, p.out + (size_t)img * p.out_img_stride);
+    }
+    }
+#undef W4_LOAD_RAW
+#undef W4_WRITE_RAW
+#undef W4_T_READ
+#undef W4_T_FMA
+#undef W4_T_COLS
+#undef W4_LOAD_U
 #if B2F_WINO_TRACE
     if (tr_on && lane == 0) tr_buf[153] = clock64();
 #endif

@@ -50,12 +50,17 @@ def conv_flops_per_px():
 def conv_executed_flops_per_px():
     """FLOPs the MFMA pipe actually executes per full-resolution pixel (2 * MAC, channel padding included):
     the stride-1 layers run as Winograd F(4x4,3x3) (>= 64 outputs: 36/16 MACs per output and channel pair,
-    channels padded to 8 in / 32 out) or F(2x2,3x3) (16..63 outputs: 16/4), the rest as direct implicit GEMM
-    (9 MACs, outputs padded to 32).  Same kernel-selection rule as b2f_api.hip:wino_mode."""
+    channels padded to 8 in / 32 out) or F(2x2,3x3) (16..31 outputs: 16/4; none in this net at the bench size), the
+    rest as direct implicit GEMM (9 MACs; outputs padded to 32, the 16 -> 16 layer exactly 16, the 2-output
+    layers run on the VALU and are not counted).  Same kernel-selection rule as b2f_api.hip:wino_mode."""
     def layer(ci, co, stride, scale):
         cip = (ci + 7) // 8 * 8
-        if stride == 1 and co >= 64 and co % 4 == 0:
+        if stride == 1 and co >= 32 and co % 4 == 0:
             macs = 36.0 / 16.0 * cip * ((co + 31) // 32 * 32)
+        elif stride == 1 and co == 2:
+            macs = 0.0
+        elif stride == 1 and ci == 16 and co == 16:
+            macs = 9.0 * 16 * 16
         elif stride == 1 and co >= 16:
             macs = 16.0 / 4.0 * cip * ((co + 31) // 32 * 32)
         else:

@@ -55,7 +55,7 @@ def test_conv3x3(hard, ci, co, stride, h, w, leaky):
     got = ops.conv3x3(hard, x, wt, b, stride, leaky)
     exp = O.conv3x3(x, wt, b, stride, leaky)
     assert got.shape == exp.shape
-    if stride == 1 and co >= 64:
+    if stride == 1 and co >= 32 and co % 4 == 0 and not (ci == 16 and co == 16):
         # Winograd F(4x4,3x3): fp32 throughout, but the transforms (coefficients up to 8) amplify rounding:
         # measured <= 6e-5 absolute on these unit-variance outputs, mean error 1e-6
         np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1.5e-4)
