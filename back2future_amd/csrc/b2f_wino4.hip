@@ -236,16 +236,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const char *wsrc = reinterpret_cast<const char *>(p.wpk) + (size_t)nb * nchunks * U_F4 * 16;
 
     f32x4 sr[3];
+    // buffer loads (scalar 128-bit resource per K segment based at this image, scalar chunk offset, one 32-bit
+    // lane offset): no address arithmetic on the VALU, one address VGPR per load
+    const __amdgpu_buffer_rsrc_t r_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
 #define W4_LOAD_RAW(c_)                                                                             \
     do {                                                                                            \
         const int c__ = (c_);                                                                       \
         const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
-        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
-        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
         const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
-        const char *ib = reinterpret_cast<const char *>(base + (size_t)img * istr + (size_t)cc * cstr); \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) sr[i] = *reinterpret_cast<const f32x4 *>(ib + s_off[i]); \
+        const int so = (int)(cc * cstr * 4);                                                        \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                               \
+            sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)s_off[i], so, 0)); \
     } while (0)
 #define W4_WRITE_RAW(buf_)                                                                          \
     do {                                                                                            \
@@ -352,7 +357,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const int a_off = (9 * g * 2 + half) * 32 + m;                       // V[xi = 9g][k4 = half][tile m]; xi+1 -> +64
     const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u; // bytes: U[xi = 9g][k4 = half][co]; xi+1 -> +2048
     f32x4 av[3], bv[3];
-#define W4_LOAD_U(slot_, c_, x_) bv[slot_] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)(c_) * (U_F4 * 16) + b_off + (x_) * 2048)
+    // buffer loads: 128-bit resource (scalar), one 32-bit lane offset, scalar (chunk, xi) offset -- no per-load
+    // address arithmetic on the VALU and one address VGPR instead of two
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
+#define W4_LOAD_U(slot_, c_, x_)                                                                    \
+    bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((c_) * (U_F4 * 16) + (x_) * 2048), 0))
 
     // Software pipeline (Tr(k) = input transform of chunk k -> V[k & 1], raw(k) = its patch in raw buffer k & 1):
     //   iteration c, xi steps 0..5 : MFMAs of xi (A operand read one step ahead, B two steps ahead),
@@ -531,9 +540,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const int a_lane = half * 32 + m;                       // V[xi][k4 = half][tile m] = xi * 64 + a_lane (float4)
     const unsigned b_lane = (half * 64 + m) * 16u;          // bytes: U[xi][k4 = half][co m] = xi * 2048 + b_lane
     f32x4 av[5], bc[5], bn[5];
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
 #define W4S_LOAD_U(dst_, c_)                                                                        \
     _Pragma("unroll") for (int x = 0; x < 5; ++x)                                                   \
-        dst_[x] = *reinterpret_cast<const f32x4 *>(wsrc + (size_t)(c_) * (U_F4 * 16) + b_lane + xo[x] * 2048)
+        dst_[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_lane, (int)((c_) * (U_F4 * 16) + xo[x] * 2048), 0))
     {
         f32x4 keep[3];
         W4_LOAD_RAW(min(1, nchunks - 1));
@@ -655,7 +665,9 @@ bool wino4_supported(const ConvLaunch &p)
     if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) return false;
     if (p.nseg > 1 && p.seg[1].pix_stride != p.seg[0].pix_stride) return false;
     if (((p.out_pix_stride | (int)p.out_chunk_stride) & 3) != 0 || (p.cout & 3) != 0) return false;   // 16-byte stores
-    return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 4294967296.0;   // 32-bit byte offsets inside a plane
+    for (int i = 0; i < p.nseg; ++i)        // signed 32-bit scalar chunk offsets of the buffer loads
+        if ((double)p.seg[i].nchunks * (double)p.seg[i].chunk_stride * 4.0 >= 2147483648.0) return false;
+    return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 2147483648.0;   // 32-bit byte offsets inside a plane
 }
 
 hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
