@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
     const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
 
     // ---- per-thread staging coordinates for the A patch (fixed over chunks) ----
-    int a_goff[A_PER_THREAD];   // pixel index inside the image (clamped to a valid pixel)
+    unsigned a_off0[A_PER_THREAD], a_off1[A_PER_THREAD];   // byte offset inside the (image, chunk) plane, per K segment
     bool a_ok[A_PER_THREAD];    // false: halo outside the image / beyond the patch -> zero fill
     int a_lds[A_PER_THREAD];
 #pragma unroll
@@ -87,13 +87,21 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
         const int py = pix / PW, px = pix - py * PW;
         const int gy = iy0 + py, gx = ix0 + px;
         a_ok[i] = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_goff[i] = a_ok[i] ? (gy * p.W + gx) : 0;   // unconditional load from a valid address, no branch
+        const unsigned gp = a_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;   // unconditional load from a valid address, no branch
+        a_off0[i] = (gp * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
+        a_off1[i] = (gp * (unsigned)p.seg[1].pix_stride + (tid & 1) * 4) * 4u;
         a_lds[i] = (idx < G::A_F4) ? (h * NPIX + pix) : -1;
     }
-    const int a_h4 = (tid & 1) * 4;
 
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
-    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.wpk) + (size_t)nb * nchunks * B_F4;
+    // buffer loads: a scalar 128-bit resource (per K segment, based at this image; the packed weights of this
+    // n-block), a scalar chunk offset and one 32-bit lane offset -- no per-load address arithmetic on the VALU
+    const __amdgpu_buffer_rsrc_t a_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.wpk + (size_t)nb * nchunks * B_F4 * 4), 0, 0x7fffffff, 0x00020000);
 
     // Staging registers.  All loops below have compile-time trip counts and compile-time
     // guards wherever a whole pass over the block fits, so the arrays stay in VGPRs and no
@@ -103,18 +111,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
     do {                                                                                            \
         const int c__ = (c_);                                                                       \
         const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
-        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
-        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
-        const int pstr = s1 ? p.seg[1].pix_stride : p.seg[0].pix_stride;                            \
         const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
-        const float *ib = base + (size_t)img * istr + (size_t)cc * cstr + a_h4;                     \
+        const int so = (int)(cc * cstr * 4);                                                        \
         _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
-            ra[i] = *reinterpret_cast<const f32x4 *>(ib + (size_t)a_goff[i] * pstr);                \
-        const f32x4 *wb = wsrc + (size_t)c__ * B_F4;                                                \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? a_rsrc1 : a_rsrc0,     \
+                                                                                    (int)(s1 ? a_off1[i] : a_off0[i]), so, 0)); \
+        const int wo = c__ * (B_F4 * 16);                                                           \
         _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
-            if ((i + 1) * NTHR <= B_F4) rb[i] = wb[tid + i * NTHR];                                 \
-            else rb[i] = wb[min(tid + i * NTHR, B_F4 - 1)];                                         \
+            if ((i + 1) * NTHR <= B_F4)                                                             \
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (tid + i * NTHR) * 16, wo, 0)); \
+            else                                                                                    \
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, min(tid + i * NTHR, B_F4 - 1) * 16, wo, 0)); \
         }                                                                                           \
     } while (0)
 #define B2F_WRITE_LDS(buf_)                                                                         \

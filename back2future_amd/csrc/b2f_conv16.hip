@@ -47,15 +47,17 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvLaunch p)
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + 4 * kg);
 
     // ---- stage the patch: item = (pixel, kg); channel quad kg lives in chunk kg >> 1, half kg & 1 ----
-    const char *src = reinterpret_cast<const char *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
     for (int i = tid; i < 4 * NPIX; i += 256) {
         const int pix = i >> 2, q = i & 3;
         const int py = pix / PW, px = pix - py * PW;
         const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-            v = *reinterpret_cast<const f32x4 *>(src + ((size_t)(q >> 1) * p.seg[0].chunk_stride +
-                                                         ((size_t)gy * p.W + gx) * p.seg[0].pix_stride + (q & 1) * 4) * 4);
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsrc, (int)(((unsigned)(gy * p.W + gx) * (unsigned)p.seg[0].pix_stride + (q & 1) * 4 +
+                             (unsigned)(q >> 1) * (unsigned)p.seg[0].chunk_stride) * 4u), 0, 0));
         patch[q][pix] = v;
     }
     __syncthreads();
@@ -89,7 +91,8 @@ bool c16_supported(const ConvLaunch &p)
 {
     return p.stride == 1 && p.cout == 16 && p.nseg == 1 && p.seg[0].nchunks == 2 && p.H == p.Ho && p.W == p.Wo &&
            (p.seg[0].pix_stride & 3) == 0 && (p.seg[0].chunk_stride & 3) == 0 && (p.out_pix_stride & 3) == 0 &&
-           (p.out_chunk_stride & 3) == 0;
+           (p.out_chunk_stride & 3) == 0 &&
+           ((double)p.H * p.W * p.seg[0].pix_stride + (double)p.seg[0].chunk_stride) * 4.0 < 2147483648.0;   // 32-bit buffer offsets
 }
 
 hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s)

@@ -138,25 +138,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char *wsrc = reinterpret_cast<const char *>(p.wpk) + (size_t)nb * nchunks * U_F4 * 16;
 
     f32x4 ra[2];
+    // buffer loads: scalar 128-bit resource (per K segment based at this image / the packed weights of this
+    // n-block), scalar chunk offset, one 32-bit lane offset -- no per-load address arithmetic on the VALU
+    const __amdgpu_buffer_rsrc_t r_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
 #define W_LOAD_RAW(c_)                                                                              \
     do {                                                                                            \
         const int c__ = (c_);                                                                       \
         const bool s1 = c__ >= p.seg[0].nchunks;                                                    \
-        const float *base = s1 ? p.seg[1].ptr : p.seg[0].ptr;                                       \
-        const long istr = s1 ? p.seg[1].img_stride : p.seg[0].img_stride;                           \
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
         const int cc = s1 ? c__ - p.seg[0].nchunks : c__;                                           \
-        const char *ib = reinterpret_cast<const char *>(base + (size_t)img * istr + (size_t)cc * cstr); \
+        const int so = (int)(cc * cstr * 4);                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
-            ra[i] = *reinterpret_cast<const f32x4 *>(ib + (s1 ? a_off1[i] : a_off0[i]));            \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0,     \
+                                                                                    (int)(s1 ? a_off1[i] : a_off0[i]), so, 0)); \
     } while (0)
     // B operands of xi pair q (xi = 4w + 2q, 4w + 2q + 1) of chunk c_: lane (m, half) loads U[xi][k4 = half][nt*32 + m]
 #define W_LOAD_U(dst_, c_, q_)                                                                      \
     do {                                                                                            \
-        const char *wb = wsrc + (size_t)(c_) * (U_F4 * 16) + (q_) * (4 * NB * 16);                  \
+        const int wo = (c_) * (U_F4 * 16) + (q_) * (4 * NB * 16);                                   \
         _Pragma("unroll") for (int x = 0; x < 2; ++x)                                               \
             _Pragma("unroll") for (int nt = 0; nt < NTV; ++nt)                                      \
-                dst_[x * NTV + nt] = *reinterpret_cast<const f32x4 *>(wb + b_off + (x * 2 * NB + nt * 32) * 16); \
+                dst_[x * NTV + nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(           \
+                    w_rsrc, (int)b_off, wo + (x * 2 * NB + nt * 32) * 16, 0));                      \
     } while (0)
 #define W_WRITE_RAW(buf_)                                                                           \
     do {                                                                                            \
