@@ -236,16 +236,41 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int no
     const float stdv[3] = {0.229f, 0.224f, 0.225f};
     const size_t hw = (size_t)H * W;
     const float *src = in + ((size_t)b * 9 + (size_t)f * 3) * hw;
-    for (int i = threadIdx.x; i < 3 * PH * PW; i += 256) {
-        const int c = i / (PH * PW), r = i - c * (PH * PW);
-        const int py = r / PW, px = r - py * PW;
-        const int gy = iy0 + py, gx = ix0 + px;
-        float v = 0.f;                                   // zero padding of the NORMALIZED image
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            v = src[(size_t)c * hw + (size_t)gy * W + gx];
-            if (normalize) v = __fdiv_rn(v + (-mean[c]), stdv[c]);   // add(-mean) then div(std)
+    // staging without integer divisions: wave w takes patch rows (c, py) = w, w + 4, ... (51 rows = 13 per wave, the
+    // row bookkeeping is scalar), lane = column 0..63, column 64 by lane 0; all loads of a wave are issued
+    // before the first one is used
+    {
+        const int lane = threadIdx.x & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        float v[13], v64[13];
+        bool ok[13], ok64[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int r = wv + 4 * i;
+            const int c = r >= 2 * PH ? 2 : (r >= PH ? 1 : 0), py = r - c * PH;
+            const int gy = iy0 + py;
+            const bool row_ok = r < 3 * PH && gy >= 0 && gy < H;
+            const float *rowp = src + (size_t)(row_ok ? c : 0) * hw + (size_t)(row_ok ? gy : 0) * W;
+            const int gx = ix0 + lane, gx64 = ix0 + 64;
+            ok[i] = row_ok && gx >= 0 && gx < W;
+            ok64[i] = row_ok && lane == 0 && gx64 < W;
+            v[i] = rowp[ok[i] ? gx : 0];
+            v64[i] = rowp[ok64[i] ? gx64 : 0];
         }
-        patch[c][py][px] = v;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int r = wv + 4 * i;
+            const int c = r >= 2 * PH ? 2 : (r >= PH ? 1 : 0), py = r - c * PH;
+            if (r < 3 * PH) {
+                float a = v[i], b = v64[i];
+                if (normalize) {                         // add(-mean) then div(std)
+                    a = __fdiv_rn(a + (-mean[c]), stdv[c]);
+                    b = __fdiv_rn(b + (-mean[c]), stdv[c]);
+                }
+                patch[c][py][lane] = ok[i] ? a : 0.f;    // zero padding of the NORMALIZED image
+                if (lane == 0) patch[c][py][64] = ok64[i] ? b : 0.f;
+            }
+        }
     }
     __syncthreads();
     const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
