@@ -334,15 +334,26 @@ __global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long
     for (int c0 = 0; c0 < nchunks; c0 += 4) {
         const int nc = min(4, nchunks - c0);
         if (c0) __syncthreads();
-        for (int i = threadIdx.x; i < nc * 2 * NP; i += 256) {
+        // all loads (clamped addresses, no branch) in flight before the first LDS write
+        constexpr int NIT = (4 * 2 * NP + 255) / 256;
+        float4 v[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
             const int c = i / (2 * NP), r = i - c * (2 * NP);
             const int pix = r >> 1, k4 = r & 1;
             const int py = pix / P, px = pix - py * P;
             const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(src + (size_t)(c0 + c) * chunk_stride + ((size_t)gy * W + gx) * pix_stride + 4 * k4);
-            patch[c][k4][pix] = v;
+            ok[k] = i < nc * 2 * NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[k] = *reinterpret_cast<const float4 *>(src + (size_t)(ok[k] ? c0 + c : 0) * chunk_stride +
+                                                     (ok[k] ? (size_t)gy * W + gx : 0) * pix_stride + 4 * k4);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int c = i / (2 * NP), r = i - c * (2 * NP);
+            if (i < nc * 2 * NP) patch[c][r & 1][r >> 1] = ok[k] ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         for (int c = 0; c < nc; ++c) {
