@@ -95,31 +95,44 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
     const float *nbr[2] = {p.nbr_fut + (size_t)b * p.img_stride, p.nbr_past + (size_t)b * p.img_stride};
 
     // ---- sampling records for the halo (once per block) ----
-    for (int i = tid; i < 2 * NHALO; i += 256) {
-        const int map = i / NHALO, hp = i - map * NHALO;
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int y = y0 - R + hy, x = x0 - R + hx;
-        float4 wgt = make_float4(0.f, 0.f, 0.f, 0.f);
-        SampIdx si;
-        si.idx = 0; si.flags = 0;
-        if (y >= 0 && y < p.h && x >= 0 && x < p.w) {
-            float u = 0.f, v = 0.f;
-            if (p.flow) {
-                const float2 f = *reinterpret_cast<const float2 *>(p.flow + ((size_t)(b * p.h + y) * p.w + x) * 2);
-                const float k = map == 0 ? p.k : -p.k;   // nn.MulConstant(20*(f-ref)/2^(l-2)), pwc.lua:404
-                u = f.x * k; v = f.y * k;
-            }
-            int xl, yt;
-            float wx, wy;
-            top_left(u + (float)x, p.w, xl, wx);
-            top_left(v + (float)y, p.h, yt, wy);
-            si.idx = (yt * p.w + xl) * p.pix_stride;   // float offset of the top-left tap inside the image plane
-            si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
-            wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
+    // 2 * NHALO = 768 = 3 records per thread; the three flow loads (clamped address, no branch) are issued
+    // together: behind a condition they were three serialized memory round trips per block
+    {
+        float2 fl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + j * 256;
+            const int map = i / NHALO, hp = i - map * NHALO;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
+            fl[j] = make_float2(0.f, 0.f);
+            if (p.flow) fl[j] = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * p.h * p.w + (in ? (size_t)y * p.w + x : 0)) * 2);
         }
-        si.flags |= (hy * HP + hx) << 2;               // LDS slot of this halo pixel
-        samp_w[map][hp] = wgt;
-        samp_i[map][hp] = si;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + j * 256;
+            const int map = i / NHALO, hp = i - map * NHALO;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            float4 wgt = make_float4(0.f, 0.f, 0.f, 0.f);
+            SampIdx si;
+            si.idx = 0; si.flags = 0;
+            if (y >= 0 && y < p.h && x >= 0 && x < p.w) {
+                const float k = map == 0 ? p.k : -p.k;   // nn.MulConstant(20*(f-ref)/2^(l-2)), pwc.lua:404
+                const float u = fl[j].x * k, v = fl[j].y * k;
+                int xl, yt;
+                float wx, wy;
+                top_left(u + (float)x, p.w, xl, wx);
+                top_left(v + (float)y, p.h, yt, wy);
+                si.idx = (yt * p.w + xl) * p.pix_stride;   // float offset of the top-left tap inside the image plane
+                si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
+                wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
+            }
+            si.flags |= (hy * HP + hx) << 2;               // LDS slot of this halo pixel
+            samp_w[map][hp] = wgt;
+            samp_i[map][hp] = si;
+        }
     }
 
     float acc[81];
