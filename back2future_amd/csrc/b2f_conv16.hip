@@ -20,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace c16 {
 constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2;
 constexpr int NPIX = PH * PW;          // 612
-constexpr int PLANE = NPIX + 4;        // float4 per channel-quad plane
+constexpr int PLANE = 628;             // float4 per channel-quad plane (>= NPIX; 628 * 16 B = 64 B mod 256: the four planes start 16 banks apart)
 }  // namespace c16
 
 __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvLaunch p)
