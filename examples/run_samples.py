@@ -26,6 +26,8 @@ def main():
     im1, im2, im3 = [flow_io.load_image(f) for f in frames]
     flow, fwd_occ, bwd_occ = computeFlow(im1, im2, im3)
     flow_io.writeFLO(prefix + ".flo", flow.astype("float32"))
+    rgb, _ = flow_io.xy2rgb(flow[0], flow[1])                       # README.md:61-63
+    flow_io.save_image(prefix + ".png", rgb)
     flow_io.save_mask(prefix + "_fwd_occ.png", fwd_occ)
     flow_io.save_mask(prefix + "_bwd_occ.png", bwd_occ)
     print("flow", flow.shape, "range", float(flow.min()), float(flow.max()),
