@@ -47,7 +47,7 @@ def test_weights_roundtrip(hard):
     (128, 192, 2, 8, 14, True), (192, 192, 1, 4, 7, True), (196, 128, 1, 16, 33, True), (32, 2, 1, 20, 17, False),
     (5, 7, 1, 3, 5, False), (64, 32, 1, 1, 2, True), (64, 64, 1, 40, 70, True), (8, 68, 1, 18, 34, False),
     (128, 128, 1, 33, 65, True), (16, 16, 1, 5, 37, False), (16, 16, 1, 35, 66, True), (32, 2, 1, 33, 18, True),
-    (40, 32, 1, 17, 33, True), (24, 96, 1, 20, 40, True)])
+    (40, 32, 1, 17, 33, True), (24, 96, 1, 20, 40, True), (16, 32, 2, 24, 40, True), (16, 32, 2, 9, 33, False)])
 def test_conv3x3(hard, ci, co, stride, h, w, leaky):
     r = _rng(ci * 1000 + co)
     x = r.standard_normal((2, ci, h, w), dtype=np.float32)
