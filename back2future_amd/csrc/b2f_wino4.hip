@@ -477,13 +477,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #endif
     float *X = reinterpret_cast<float *>(smem);
     float *ob = p.out + (size_t)img * p.out_img_stride;
+    // 72 ds_write2st64_b32 per thread instead of 144 ds_write_b32 (b32 LDS writes run at 64 B/clk): rows r and
+    // r + 4 of an accumulator land 8 tiles = 4 x 64 dwords apart, the xi planes 16 x 64 dwords apart, so one
+    // base address per (r & 3) covers the whole dump through the two 8-bit offsets.  Inline asm (the compiler
+    // pairs only a few of them): the barrier that follows must wait for lgkmcnt itself (W4_LDS_BARRIER).
+    unsigned dump_base[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dump_base[e] = 4u * (unsigned)((9 * g * 32 + ((e + 4 * half) ^ half)) * 32 + m);
 #define W4_DUMP_ACC(tag_)                                                                           \
     asm volatile("; accumulators of N tile %0 -> LDS" ::"n"(tag_));                                 \
     _Pragma("unroll") for (int x = 0; x < 9; ++x)                                                   \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
-            const int t = ((r & 3) + 8 * (r >> 2) + 4 * half) ^ half;                               \
-            X[((9 * g + x) * 32 + t) * 32 + m] = acc[x][r];                                         \
-        }
+        _Pragma("unroll") for (int qq = 0; qq < 4; qq += 2)                                         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                           \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"                   \
+                             :: "v"(dump_base[e]), "v"(acc[x][4 * qq + e]), "v"(acc[x][4 * (qq + 1) + e]), \
+                                "n"(x * 16 + qq * 4), "n"(x * 16 + qq * 4 + 4) : "memory")
     // W4_LDS_BARRIER: barrier that orders LDS traffic only.  __syncthreads() is also a release fence: after
     // the output stage it would hold the barrier until every global store of the tile has been acknowledged
     // (measured: ~25000 cycles per tile), although the next tile only needs the LDS reads to be over.
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     if (n == 0) {
         W4_DUMP_ACC(0);
         W4_E(0);
-        __syncthreads();
+        W4_LDS_BARRIER();
         W4_E(1);
         wino4_output_tile<0>(X, p, tid & 255, nb * 64, oy0, ox0, ob);
         W4_E(2);
