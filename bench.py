@@ -47,43 +47,65 @@ def conv_flops_per_px():
     return feat + flow + occ3
 
 
-def conv_executed_flops_per_px():
-    """FLOPs the MFMA pipe actually executes per full-resolution pixel (2 * MAC, channel padding included):
-    the stride-1 layers run as Winograd F(4x4,3x3) (>= 64 outputs: 36/16 MACs per output and channel pair,
-    channels padded to 8 in / 32 out) or F(2x2,3x3) (16..31 outputs: 16/4; none in this net at the bench size), the
-    rest as direct implicit GEMM (9 MACs; outputs padded to 32, the 16 -> 16 layer exactly 16, the 2-output
-    layers run on the VALU and are not counted).  Same kernel-selection rule as b2f_api.hip:wino_mode."""
-    def layer(ci, co, stride, scale):
-        cip = (ci + 7) // 8 * 8
-        if stride == 1 and co >= 32 and co % 4 == 0:
-            macs = 36.0 / 16.0 * cip * ((co + 31) // 32 * 32)
-        elif stride == 1 and co == 2:
-            macs = 0.0
-        elif stride == 1 and ci == 16 and co == 16:
-            macs = 9.0 * 16 * 16
-        elif stride == 1 and co >= 16:
-            macs = 16.0 / 4.0 * cip * ((co + 31) // 32 * 32)
-        else:
-            macs = 9.0 * cip * ((co + 31) // 32 * 32)
-        return 2.0 * macs * scale
-    total = 0.0
+def conv_layers(H, W):
+    """Every conv of the pruned computeFlow graph as (cin, cout, stride, out_h, out_w, calls per triplet): the three
+    siamese towers, the flow decoders of levels 7..3 and the occlusion decoder of level 3."""
+    out = []
     for l in range(2, 8):
-        s_out = 1.0 / 4 ** (l - 1)
-        if l > 2:                                            # level 2's first conv is the fused VALU conv_first kernel
-            total += 3 * layer(FEAT[l - 1], FEAT[l], 2, s_out)
-        total += 3 * layer(FEAT[l], FEAT[l], 1, s_out)
-
-    def dec(n, s_out):
-        ci, t = n, 0.0
+        h, w = H >> (l - 1), W >> (l - 1)
+        out.append((FEAT[l - 1], FEAT[l], 2, h, w, 3))
+        out.append((FEAT[l], FEAT[l], 1, h, w, 3))
+    for l in range(7, 2, -1):
+        h, w = H >> (l - 1), W >> (l - 1)
+        ci = 162 if l == 7 else 162 + FEAT[l] + 2
         for co in DEC:
-            t += layer(ci, co, 1, s_out)
+            out.append((ci, co, 1, h, w, 2 if l == 3 else 1))
             ci = co
-        return t
-    for l in range(3, 8):
-        n = 168 if l == 7 else 168 + FEAT[l]                 # cost-volume record (168 slots) + reference features
-        total += dec(n, 1.0 / 4 ** (l - 1))
-    total += dec(168 + FEAT[3], 1.0 / 16)                    # level-3 occlusion decoder
-    return total
+    return out
+
+
+def conv_kernel_of(ci, co, stride, h, w):
+    """Kernel class a layer runs on -- the rule of b2f_api.hip (wino_mode, run_conv) with the default switches."""
+    if ci == 3:
+        return "conv_first"
+    if stride == 1 and co == 2:
+        return "conv3x3_narrow2"
+    if stride == 1 and ci == 16 and co == 16:
+        return "conv3x3_c16"
+    if stride == 1 and co >= 32 and co % 4 == 0:
+        return "conv3x3_wino4" if h * w >= 4096 else "conv3x3_wino"
+    if stride == 1 and co >= 16:
+        return "conv3x3_wino"
+    return "conv3x3_s%d" % stride
+
+
+def conv_flops_by_kernel(H, W):
+    """Per kernel class and triplet: (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes).  Executed:
+    F(4x4) 36/16 MACs per output and channel pair, F(2x2) 16/4, direct 9; input channels padded to 8 (the decoder's
+    first layer reads the 168-slot cost-volume record), outputs to 32 (16 for the 16 -> 16 kernel); VALU kernels 0."""
+    alg, exe = {}, {}
+    for ci, co, stride, h, w, calls in conv_layers(H, W):
+        k = conv_kernel_of(ci, co, stride, h, w)
+        n = float(h * w * calls)
+        cip = (ci + 7) // 8 * 8
+        if ci >= 162:
+            cip = 168 + (ci - 162 - 2 if ci > 162 else 0)          # record (168 slots, flow inside) + reference features
+        cop = (co + 31) // 32 * 32
+        per_out = {"conv3x3_wino4": 36.0 / 16.0, "conv3x3_wino": 16.0 / 4.0}.get(k, 9.0)
+        e = 2.0 * per_out * cip * cop
+        if k in ("conv_first", "conv3x3_narrow2"):
+            e = 0.0
+        if k == "conv3x3_c16":
+            e = 2.0 * 9.0 * 16 * 16
+        alg[k] = alg.get(k, 0.0) + 2.0 * 9.0 * ci * co * n
+        exe[k] = exe.get(k, 0.0) + e * n
+    return alg, exe
+
+
+def conv_executed_flops_per_px():
+    """FLOPs the MFMA pipe actually executes per full-resolution pixel at the bench size (see conv_flops_by_kernel)."""
+    _, exe = conv_flops_by_kernel(1024, 1920)
+    return sum(exe.values()) / (1024.0 * 1920.0)
 
 
 def corr_bytes_per_px():
@@ -240,19 +262,34 @@ def main():
             corr_ms /= args.steps
             corr_n /= args.steps
             tr = pmc_traffic(B, H, W)
-            flops = conv_flops_per_px() * px
-            a = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-            ex = conv_executed_flops_per_px() * px
-            ea = ex / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-            out["roofline"] = {"kernel": "conv3x3 (Winograd F(4x4)/F(2x2) + direct fp32-MFMA kernels, conv_first; all %d conv launches of a step)" % conv_n,
-                               "bound": "mfma",
-                               "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
-                               "note": "achieved = algorithmic direct-convolution FLOPs / time; the Winograd kernels execute 4x / 2.25x "
-                                       "fewer MACs, so frac may exceed 1 -- mfma_executed is the utilisation of the matrix pipe itself",
-                               "mfma_executed": {"achieved": ea, "unit": "TFLOP/s", "frac": ea / 157.3, "flop_per_step": ex},
-                               "traffic": tr.get("conv", {}).get("traffic_bytes"), "traffic_unit": "HBM bytes per step (PMC)",
-                               "traffic_source": tr.get("file"), "ms_per_step": conv_ms,
-                               "algorithmic_flop_per_step": flops}
+            alg_k, exe_k = conv_flops_by_kernel(H, W)
+            kms = {}
+            for k, (ms, n) in prof.items():                      # profile rows -> kernel classes (rows carry an _ntN suffix)
+                for cls in alg_k:
+                    if k == cls or k.startswith(cls + "_"):
+                        kms[cls] = kms.get(cls, 0.0) + ms / args.steps
+            dom = max(kms, key=kms.get)                          # dominant kernel class of the step
+            d_alg, d_exe, d_ms = alg_k[dom] * B, exe_k[dom] * B, kms[dom]
+            a = d_alg / (d_ms * 1e-3) / 1e12
+            ea = d_exe / (d_ms * 1e-3) / 1e12
+            note = ("achieved = algorithmic direct-convolution FLOPs of the layers this kernel runs / its time; Winograd F(4x4) "
+                    "executes 4x fewer MACs (F(2x2): 2.25x), so frac may exceed 1 -- mfma_executed is the utilisation of the "
+                    "matrix pipe itself")
+            out["roofline"] = {"kernel": "%s (Winograd F(4x4,3x3) on the fp32 MFMA; %.0f %% of the step)" % (dom, 100.0 * d_ms / (1e3 * dt / args.steps))
+                               if dom == "conv3x3_wino4" else dom,
+                               "bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3, "note": note,
+                               "mfma_executed": {"achieved": ea, "unit": "TFLOP/s", "frac": ea / 157.3, "flop_per_step": d_exe},
+                               "traffic": tr.get(dom, {}).get("traffic_bytes"), "traffic_unit": "HBM bytes per step (PMC)",
+                               "traffic_source": tr.get("file"), "ms_per_step": d_ms, "algorithmic_flop_per_step": d_alg}
+            flops = sum(alg_k.values()) * B
+            ex = sum(exe_k.values()) * B
+            a_all = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            e_all = ex / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+            out["roofline_conv_all"] = {"kernel": "all %d conv launches of a step" % conv_n, "bound": "mfma", "achieved": a_all,
+                                        "peak": 157.3, "unit": "TFLOP/s", "frac": a_all / 157.3,
+                                        "mfma_executed": {"achieved": e_all, "unit": "TFLOP/s", "frac": e_all / 157.3, "flop_per_step": ex},
+                                        "traffic": tr.get("conv", {}).get("traffic_bytes"), "traffic_unit": "HBM bytes per step (PMC)",
+                                        "traffic_source": tr.get("file"), "ms_per_step": conv_ms, "algorithmic_flop_per_step": flops}
             cb = corr_bytes_per_px() * px
             g = cb / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
             out["roofline_corrwarp"] = {"kernel": "warp_costvol (%d launches of a step)" % corr_n, "bound": "hbm",
