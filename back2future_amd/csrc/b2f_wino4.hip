@@ -65,9 +65,6 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 #ifndef B2F_WINO_TRACE
 #define B2F_WINO_TRACE 0
 #endif
-#ifndef B2F_WINO4_SETPRIO
-#define B2F_WINO4_SETPRIO 0
-#endif
 // Profiling only (results are wrong): -DB2F_WINO4_ABLATE=bits, 1 no input transform, 2 no raw staging, 4 no B loads,
 // 8 no MFMAs, 16 no A operand reads
 #ifndef B2F_WINO4_ABLATE
@@ -356,7 +353,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     const bool mf_on = n < NTV;                                          // this wave's N tile holds real channels
     const int a_off = (9 * g * 2 + half) * 32 + m;                       // V[xi = 9g][k4 = half][tile m]; xi+1 -> +64
     const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u; // bytes: U[xi = 9g][k4 = half][co]; xi+1 -> +2048
-    f32x4 av[3], bv[3];
+    f32x4 av[3], bv[6];
     // buffer loads: 128-bit resource (scalar), one 32-bit lane offset, scalar (chunk, xi) offset -- no per-load
     // address arithmetic on the VALU and one address VGPR instead of two
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
@@ -378,7 +375,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #pragma unroll
         for (int i = 0; i < 3; ++i) keep[i] = sr[i];
         W4_LOAD_RAW(0);
-        if (NTV == 2 || mf_on) { W4_LOAD_U(0, 0, 0); W4_LOAD_U(1, 0, 1); }
+        if (NTV == 2 || mf_on) { W4_LOAD_U(0, 0, 0); W4_LOAD_U(1, 0, 1); W4_LOAD_U(2, 0, 2); W4_LOAD_U(3, 0, 3); W4_LOAD_U(4, 0, 4); }
         W4_WRITE_RAW(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) sr[i] = keep[i];
@@ -404,66 +401,71 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #if B2F_WINO_TRACE
     if (tr_on && lane == 0) { tr_buf[150] = t_start; tr_buf[151] = clock64(); }
 #endif
-    for (int c = 0; c < nchunks; ++c) {
-        W4_T(0);
-        const int cn = min(c + 1, nchunks - 1);
-        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
-        const f32x4 *Vn = Vb + ((c + 1) & 1) * V_F4 + a_off;
-#pragma unroll
-        for (int x = 0; x < 9; ++x) {
-            // B operand two xi ahead (next chunk's for x >= 7); A operand one xi ahead (xi 8 two ahead, so that
-            // every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it)
-            if (!(B2F_WINO4_ABLATE & 4) && (NTV == 2 || mf_on)) {
-                if (x + 2 < 9) W4_LOAD_U((x + 2) % 3, c, x + 2);
-                else if (x == 8) W4_LOAD_U(1, cn, 1);
-                // (the load of xi 0 of the next chunk, due at x == 7, is issued at the end of step 6, ahead of the
-                // raw loads: s_waitcnt vmcnt is in order, every B operand fetched after them waits for HBM)
-            }
-            if (!(B2F_WINO4_ABLATE & 16)) {
-                if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];
-                if (x == 6) av[8 % 3] = Vc[8 * 64];
-                if (x == 7) av[0] = Vn[0];
-                if (x == 8) av[1] = Vn[64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(B2F_WINO4_ABLATE & 8) && (NTV == 2 || mf_on)) {
-#if B2F_WINO4_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[x % 3][j], acc[x], 0, 0, 0);
-#if B2F_WINO4_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (x < 6) {
-                // slice x + 2 of Tr(c+1) (its reads were issued one step ago), then the reads of the next slice
-                if (!(B2F_WINO4_ABLATE & 1)) {
-                    W4_T_FMA(x + 2);
-                    if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);
-                }
-            } else if (x == 6) {
-                if (!(B2F_WINO4_ABLATE & 1)) W4_T_COLS((c + 1) & 1);
-                if (!(B2F_WINO4_ABLATE & 2)) W4_WRITE_RAW(c & 1);
-                if (!(B2F_WINO4_ABLATE & 4) && (NTV == 2 || mf_on)) W4_LOAD_U(0, cn, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                W4_T(3);
-                __syncthreads();
-                W4_T(4);
-                if (!(B2F_WINO4_ABLATE & 1)) W4_T_READ(0, c & 1);   // Tr(c+2), raw(c+2) is in raw buffer c & 1
-                if (!(B2F_WINO4_ABLATE & 2)) W4_LOAD_RAW(min(c + 3, nchunks - 1));
-            } else if (x == 7) {
-                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(0); W4_T_READ(1, c & 1); }
-            } else {
-                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(1); W4_T_READ(2, c & 1); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (x == 2) W4_T(1);
-            if (x == 5) W4_T(2);
+    // One chunk of the software pipeline as a macro with the phase PH_ of the B ring as a compile-time
+    // parameter: the ring has 6 slots and runs 5 xi ahead (9 xi per chunk, so the slot pattern repeats every
+    // two chunks: the loop below is unrolled by two, an odd last chunk reuses phase 0).  Five xi of lookahead
+    // = ~2500 cycles between a B load and its use: the B loads queued behind the raw-patch loads (HBM latency,
+    // s_waitcnt vmcnt is in order) no longer stall the MFMAs of both waves of a SIMD at the start of a chunk.
+#define W4_CHUNK(PH_, c_)                                                                           \
+    do {                                                                                            \
+        const int c = (c_);                                                                         \
+        W4_T(0);                                                                                    \
+        const int cn = min(c + 1, nchunks - 1);                                                     \
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;                                              \
+        const f32x4 *Vn = Vb + ((c + 1) & 1) * V_F4 + a_off;                                        \
+        _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
+            /* B operand five xi ahead (next chunk's for x >= 4); A operand one xi ahead (xi 8 two ahead, so */ \
+            /* that every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it) */ \
+            if (!(B2F_WINO4_ABLATE & 4) && (NTV == 2 || mf_on)) {                                   \
+                if (x + 5 < 9) W4_LOAD_U((9 * (PH_) + x + 5) % 6, c, x + 5);                        \
+                else W4_LOAD_U((9 * (PH_) + x + 5) % 6, cn, x + 5 - 9);                             \
+            }                                                                                       \
+            if (!(B2F_WINO4_ABLATE & 16)) {                                                         \
+                if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                           \
+                if (x == 6) av[8 % 3] = Vc[8 * 64];                                                 \
+                if (x == 7) av[0] = Vn[0];                                                          \
+                if (x == 8) av[1] = Vn[64];                                                         \
+            }                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if (!(B2F_WINO4_ABLATE & 8) && (NTV == 2 || mf_on)) {                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[(9 * (PH_) + x) % 6][j], acc[x], 0, 0, 0); \
+            }                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if (x < 6) {                                                                            \
+                /* slice x + 2 of Tr(c+1) (its reads were issued one step ago), then the reads of the next slice */ \
+                if (!(B2F_WINO4_ABLATE & 1)) {                                                      \
+                    W4_T_FMA(x + 2);                                                                \
+                    if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);                                   \
+                }                                                                                   \
+            } else if (x == 6) {                                                                    \
+                if (!(B2F_WINO4_ABLATE & 1)) W4_T_COLS((c + 1) & 1);                                \
+                if (!(B2F_WINO4_ABLATE & 2)) W4_WRITE_RAW(c & 1);                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4_T(3);                                                                            \
+                __syncthreads();                                                                    \
+                W4_T(4);                                                                            \
+                if (!(B2F_WINO4_ABLATE & 1)) W4_T_READ(0, c & 1);   /* Tr(c+2), raw(c+2) is in raw buffer c & 1 */ \
+                if (!(B2F_WINO4_ABLATE & 2)) W4_LOAD_RAW(min(c + 3, nchunks - 1));                  \
+            } else if (x == 7) {                                                                    \
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(0); W4_T_READ(1, c & 1); }                  \
+            } else {                                                                                \
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(1); W4_T_READ(2, c & 1); }                  \
+            }                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if (x == 2) W4_T(1);                                                                    \
+            if (x == 5) W4_T(2);                                                                    \
+        }                                                                                           \
+    } while (0)
+    {
+        int c2 = 0;
+        for (; c2 + 1 < nchunks; c2 += 2) {
+            W4_CHUNK(0, c2);
+            W4_CHUNK(1, c2 + 1);
         }
+        if (c2 < nchunks) W4_CHUNK(0, c2);
     }
+#undef W4_CHUNK
 
     // ---- output, one N tile at a time (LDS holds the 36 planes of 32 channels: 144 KB): the four waves of
     // the tile write their accumulators to X[xi][tile row][co 32] (tile rows t and t ^ 1 swapped when bit 2
