@@ -530,6 +530,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #undef W4_E
 #undef W4_LDS_BARRIER
 #undef W4_DUMP_ACC
+#if B2F_WINO_TRACE
+    if (tr_on && lane == 0) tr_buf[153] = clock64();
+#endif
     } else {
     // =====================================================================================================
     // Single N tile (NTV == 1: the last n-block of a layer whose cout is 32 mod 64): the 36 xi are split over
@@ -616,9 +619,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #undef W4_T_FMA
 #undef W4_T_COLS
 #undef W4_LOAD_U
-#if B2F_WINO_TRACE
-    if (tr_on && lane == 0) tr_buf[153] = clock64();
-#endif
 }
 
 template <int NTV>
