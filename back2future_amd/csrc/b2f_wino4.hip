@@ -586,7 +586,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             if (x < 4) { W4_T_READ_D(2 * x, (c + 1) & 1, 0); W4_T_READ_D(2 * x + 1, (c + 1) & 1, 3); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                if (x < 4 || n == 0)       // the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch)
+                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (x < 4) { W4_T_FMA_D(2 * x, 0); W4_T_FMA_D(2 * x + 1, 3); }
             else { W4_T_COLS((c + 1) & 1); W4_WRITE_RAW(c & 1); }
