@@ -109,13 +109,21 @@ class Model(object):
             bwd.ctypes.data_as(C.POINTER(C.c_ubyte))))
         return flow, fwd, bwd
 
-    def computeFlowBatch(self, im1, im2, im3):
-        """n independent triplets at once: inputs n x 3 x H x W."""
+    def computeFlowBatch(self, im1, im2, im3, out=None):
+        """n independent triplets at once: inputs n x 3 x H x W.  The library pipelines sub-batches through
+        pinned staging buffers; inputs / `out` = (flow f64 n x 2 x H x W, fwd u8 n x 1 x H x W, bwd) that already
+        live in page-locked memory (e.g. views of torch pin_memory() tensors) are DMA'd in place instead."""
         im1, im2, im3 = _lib.f32(im1), _lib.f32(im2), _lib.f32(im3)
         n, _, H0, W0 = im1.shape
-        flow = np.empty((n, 2, H0, W0), np.float64)
-        fwd = np.empty((n, 1, H0, W0), np.uint8)
-        bwd = np.empty((n, 1, H0, W0), np.uint8)
+        if out is not None:
+            flow, fwd, bwd = out
+            assert flow.dtype == np.float64 and flow.shape == (n, 2, H0, W0) and flow.flags.c_contiguous
+            for m in (fwd, bwd):
+                assert m.dtype == np.uint8 and m.shape == (n, 1, H0, W0) and m.flags.c_contiguous
+        else:
+            flow = np.empty((n, 2, H0, W0), np.float64)
+            fwd = np.empty((n, 1, H0, W0), np.uint8)
+            bwd = np.empty((n, 1, H0, W0), np.uint8)
         _lib.check(_lib.lib().b2f_compute_flow_batch(
             self._h, n, _lib.fptr(im1), _lib.fptr(im2), _lib.fptr(im3), H0, W0,
             flow.ctypes.data_as(C.POINTER(C.c_double)), fwd.ctypes.data_as(C.POINTER(C.c_ubyte)),

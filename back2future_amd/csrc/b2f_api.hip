@@ -4,12 +4,17 @@
 #include "../../include/b2f.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -66,6 +71,98 @@ struct GraphKey {
     }
 };
 
+// One of the two buffer sets the host-buffer entry point (b2f_compute_flow_batch) alternates between: while the
+// kernels of sub-batch k run on set k & 1, the uploads of k + 1 and the downloads of k - 1 use the other one.
+struct HostSlot {
+    char *dev = nullptr;        // device blob, carved below
+    size_t dev_bytes = 0;
+    char *pin = nullptr;        // pinned staging blob (only touched when the caller's buffers are pageable)
+    size_t pin_bytes = 0;
+    float *d_up = nullptr, *d_tmp = nullptr, *d_in = nullptr, *d_flow = nullptr, *d_est3 = nullptr;
+    double *d_oflow = nullptr;
+    unsigned char *d_fo = nullptr, *d_bo = nullptr;
+    float *h_in = nullptr;
+    double *h_oflow = nullptr;
+    unsigned char *h_fo = nullptr, *h_bo = nullptr;
+    hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+};
+
+struct CopyJob {
+    void *dst;
+    const void *src;
+    size_t bytes;
+};
+
+// Persistent host threads that memcpy job lists in 1 MB pieces (the caller's thread works too).  One core moves
+// ~10 GB/s; a full-HD triplet is 71 MB in and 35 MB out, so a single-threaded staging copy would cost several
+// times the 1.5 ms the GPU needs for it.
+class CopyPool {
+public:
+    explicit CopyPool(int workers)
+    {
+        for (int i = 0; i < workers; ++i) th_.emplace_back([this] { worker(); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    int workers() const { return (int)th_.size(); }
+    void run(const std::vector<CopyJob> &jobs)
+    {
+        constexpr size_t kPiece = 1 << 20;
+        std::vector<CopyJob> pieces;
+        size_t bytes = 0;
+        for (const CopyJob &j : jobs) {
+            for (size_t o = 0; o < j.bytes; o += kPiece)
+                pieces.push_back({(char *)j.dst + o, (const char *)j.src + o, std::min(kPiece, j.bytes - o)});
+            bytes += j.bytes;
+        }
+        if (th_.empty() || bytes < (2u << 20)) {
+            for (const CopyJob &j : pieces) memcpy(j.dst, j.src, j.bytes);
+            return;
+        }
+        std::unique_lock<std::mutex> l(m_);
+        pieces_ = &pieces;
+        next_ = done_ = 0;
+        cv_.notify_all();
+        while (next_ < pieces.size()) {
+            const CopyJob j = pieces[next_++];
+            l.unlock();
+            memcpy(j.dst, j.src, j.bytes);
+            l.lock();
+            ++done_;
+        }
+        cv_done_.wait(l, [&] { return done_ == pieces.size(); });
+        pieces_ = nullptr;
+    }
+
+private:
+    void worker()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [&] { return stop_ || (pieces_ && next_ < pieces_->size()); });
+            if (stop_) return;
+            const CopyJob j = (*pieces_)[next_++];
+            l.unlock();
+            memcpy(j.dst, j.src, j.bytes);
+            l.lock();
+            if (++done_ == pieces_->size()) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const std::vector<CopyJob> *pieces_ = nullptr;
+    size_t next_ = 0, done_ = 0;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 struct b2f_ctx {
@@ -92,6 +189,10 @@ struct b2f_ctx {
     std::vector<long long> prof_n;
     std::vector<ProfEvent> prof_pending;
     std::vector<hipEvent_t> ev_pool;
+    // host-buffer pipeline (b2f_compute_flow_batch)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    HostSlot slot[2];
+    std::unique_ptr<CopyPool> pool_in, pool_out;
 };
 
 namespace {
@@ -699,6 +800,14 @@ void b2f_destroy(b2f_ctx *c)
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
     for (ProfEvent &pe : c->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (HostSlot &hs : c->slot) {
+        if (hs.dev) (void)hipFree(hs.dev);
+        if (hs.pin) (void)hipHostFree(hs.pin);
+        for (hipEvent_t e : {hs.ev_in, hs.ev_comp, hs.ev_out})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->arena) (void)hipFree(c->arena);
     if (c->wpk_dev) (void)hipFree(c->wpk_dev);
     if (c->w_dev) (void)hipFree(c->w_dev);
@@ -830,6 +939,85 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
     return forward_impl(c, s, false, dev_in, in_kind, P, O);
 }
 
+// ---- host-buffer entry point: a double-buffered upload / compute / download pipeline ----------------
+namespace {
+
+// true when [p, p + bytes) is page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister,
+// e.g. a torch pin_memory() tensor): such buffers are DMA'd directly, pageable ones go through the pinned slot
+bool is_pinned(const void *p, size_t bytes)
+{
+    for (const char *q : {(const char *)p, (const char *)p + bytes - 1}) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// carve the slot's device and pinned blobs for sub-batches of up to SB triplets; grows (never shrinks) the blobs
+int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0, int fw, bool same, int C3, bool stage_in,
+                bool stage_out)
+{
+    const size_t n_up = align256((size_t)SB * 9 * hw0 * 4), n_in = same ? 0 : align256((size_t)SB * 9 * hw * 4),
+                 n_tmp = same ? 0 : align256((size_t)SB * 9 * H0 * fw * 4), n_flow = align256((size_t)SB * 2 * hw * 4),
+                 n_est3 = align256((size_t)SB * C3 * hw * 4), n_of = align256((size_t)SB * 2 * hw0 * 8),
+                 n_occ = align256((size_t)SB * hw0);
+    const size_t need_dev = n_up + n_in + n_tmp + n_flow + n_est3 + n_of + 2 * n_occ;
+    if (need_dev > hs.dev_bytes) {
+        if (hs.dev) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(hs.dev));
+            hs.dev = nullptr; hs.dev_bytes = 0;
+            for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);   // graphs are keyed on slot pointers
+            c->graphs.clear();
+        }
+        HIPCHK(hipMalloc(&hs.dev, need_dev));
+        hs.dev_bytes = need_dev;
+    }
+    char *d = hs.dev;
+    hs.d_up = (float *)d; d += n_up;
+    hs.d_in = same ? hs.d_up : (float *)d; d += n_in;
+    hs.d_tmp = (float *)d; d += n_tmp;
+    hs.d_flow = (float *)d; d += n_flow;
+    hs.d_est3 = (float *)d; d += n_est3;
+    hs.d_oflow = (double *)d; d += n_of;
+    hs.d_fo = (unsigned char *)d; d += n_occ;
+    hs.d_bo = (unsigned char *)d;
+    const size_t need_pin = (stage_in ? n_up : 0) + (stage_out ? n_of + 2 * n_occ : 0);
+    if (need_pin > hs.pin_bytes) {
+        if (hs.pin) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipHostFree(hs.pin));
+            hs.pin = nullptr; hs.pin_bytes = 0;
+        }
+        HIPCHK(hipHostMalloc(&hs.pin, need_pin, hipHostMallocDefault));
+        hs.pin_bytes = need_pin;
+    }
+    char *h = hs.pin;
+    hs.h_in = (float *)h; h += stage_in ? n_up : 0;
+    hs.h_oflow = (double *)h; h += stage_out ? n_of : 0;
+    hs.h_fo = (unsigned char *)h; h += stage_out ? n_occ : 0;
+    hs.h_bo = (unsigned char *)h;
+    for (hipEvent_t *e : {&hs.ev_in, &hs.ev_comp, &hs.ev_out})
+        if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return 0;
+}
+
+}  // namespace
+
+// The n triplets are cut into sub-batches (B2F_HOST_SUBBATCH_PIXELS input pixels each, default 8 Mpx = four
+// full-HD triplets) that flow through two buffer sets on three streams: uploads on s_in, ColorNormalize /
+// image.scale / the network / the nearest rescale + thresholds on the context's stream, downloads on s_out.
+// A buffer set's input half is reused as soon as the kernels that read it are done and its output half as soon
+// as its download has been handed over, so in steady state all three streams are busy.  Host threads only copy
+// between the caller's buffers and the pinned sets (B2F_HOST_THREADS, default 16, two thirds of them on the
+// input side; the output side is drained by a second control thread) -- and not even that when the caller's
+// buffers are already page-locked.
 int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
                            int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
 {
@@ -837,51 +1025,135 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
     if (n <= 0 || H0 <= 0 || W0 <= 0) return fail("b2f_compute_flow: bad shape");
     const int fw = W0 - W0 % 64, fh = H0 - H0 % 64;   // back2future.lua:54-67
     if (fw <= 0 || fh <= 0) return fail("b2f_compute_flow: image smaller than 64 pixels");
+    CHK(check_shape(1, fh, fw));
     HIPCHK(hipSetDevice(c->device));
     const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
     const bool same = (fw == W0 && fh == H0);
-    // torch.cat + (ColorNormalize) + image.scale (:48-71).  When no rescale is needed the raw
-    // [0,1] planes go up as they are and are normalized on the device; otherwise normalize and
-    // box-filter on the host exactly in the reference's order (normalize, then scale).
-    std::vector<float> stage((size_t)n * 9 * hw);
-    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-    std::vector<float> tmp;
-    if (!same) tmp.resize(9 * hw0);
-    for (int b = 0; b < n; ++b) {
-        const float *src[3] = {im1 + (size_t)b * 3 * hw0, im2 + (size_t)b * 3 * hw0, im3 + (size_t)b * 3 * hw0};
-        float *dst = stage.data() + (size_t)b * 9 * hw;
-        if (same) {
-            for (int f = 0; f < 3; ++f) memcpy(dst + (size_t)f * 3 * hw, src[f], 3 * hw * sizeof(float));
-        } else {
-            for (int f = 0; f < 3; ++f)
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float *s = src[f] + (size_t)ch * hw0;
-                    float *t = tmp.data() + ((size_t)f * 3 + ch) * hw0;
-                    for (size_t i = 0; i < hw0; ++i) t[i] = (s[i] + (-mean[ch])) / stdv[ch];
-                }
-            image_scale_bilinear(tmp.data(), 9, H0, W0, dst, fh, fw);
-        }
-    }
     const int C3 = c->past_flow ? 2 : 3;
-    float *d_in = nullptr, *d_flow = nullptr, *d_est3 = nullptr;
-    HIPCHK(hipMalloc(&d_in, stage.size() * sizeof(float)));
-    HIPCHK(hipMalloc(&d_flow, (size_t)n * 2 * hw * sizeof(float)));
-    HIPCHK(hipMalloc(&d_est3, (size_t)n * C3 * hw * sizeof(float)));
+    const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (8ll << 20);
+    const int nthreads = std::max(2, getenv("B2F_HOST_THREADS") ? atoi(getenv("B2F_HOST_THREADS"))
+                                                                 : (int)std::min(16u, std::thread::hardware_concurrency()));
+    const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
+    const int nsub = (n + SB - 1) / SB;
+
+    if (!c->s_in) HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    if (!c->s_out) HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    const bool stage_in = !(is_pinned(im1, (size_t)n * 3 * hw0 * 4) && is_pinned(im2, (size_t)n * 3 * hw0 * 4) &&
+                            is_pinned(im3, (size_t)n * 3 * hw0 * 4));
+    const bool stage_out = !(is_pinned(flow, (size_t)n * 2 * hw0 * 8) && is_pinned(fwd_occ, (size_t)n * hw0) &&
+                             is_pinned(bwd_occ, (size_t)n * hw0));
+    for (int k = 0; k < std::min(nsub, 2); ++k)
+        CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_out));
+    // the calling thread and the drain thread each count as one copier of their pool
+    const int w_out = std::max(0, nthreads / 3 - 1), w_in = std::max(0, nthreads - nthreads / 3 - 1);
+    if (stage_in && (!c->pool_in || c->pool_in->workers() != w_in)) c->pool_in.reset(new CopyPool(w_in));
+    if (stage_out && (!c->pool_out || c->pool_out->workers() != w_out)) c->pool_out.reset(new CopyPool(w_out));
+
+    const float *ims[3] = {im1, im2, im3};
+    // ---- output side: a second control thread hands finished downloads to the caller ----
+    std::mutex mu;
+    std::condition_variable cv;
+    int submitted = 0, drained = 0;   // sub-batches whose downloads are enqueued / copied out (guarded by mu)
+    bool abort = false;
+    std::string drain_err;
+    auto drain_loop = [&]() {
+        (void)hipSetDevice(c->device);
+        for (int k = 0; k < nsub; ++k) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return submitted > k || abort; });
+                if (abort) return;
+            }
+            HostSlot &hs = c->slot[k & 1];
+            const hipError_t e = hipEventSynchronize(hs.ev_out);
+            if (e == hipSuccess) {
+                const size_t b0 = (size_t)k * SB, nb = std::min<size_t>(SB, n - b0);
+                c->pool_out->run({{flow + b0 * 2 * hw0, hs.h_oflow, nb * 2 * hw0 * 8},
+                                  {fwd_occ + b0 * hw0, hs.h_fo, nb * hw0},
+                                  {bwd_occ + b0 * hw0, hs.h_bo, nb * hw0}});
+            }
+            std::lock_guard<std::mutex> l(mu);
+            if (e != hipSuccess) {
+                drain_err = std::string("download failed: ") + hipGetErrorString(e);
+                abort = true;
+            }
+            drained = k + 1;
+            cv.notify_all();
+            if (abort) return;
+        }
+    };
+    std::thread drainer;
+    if (stage_out) drainer = std::thread(drain_loop);
+
+    auto submit = [&](int k) -> int {
+        HostSlot &hs = c->slot[k & 1];
+        const size_t b0 = (size_t)k * SB;
+        const int nb = (int)std::min<size_t>(SB, n - b0);
+        // ---- upload: torch.cat({im1, im2, im3}, 1) (back2future.lua:48) = [triplet][frame][3][H0][W0] on the device.
+        // The set's staging buffer is free once upload k - 2 has left it, its device buffer once the kernels of
+        // k - 2 are done (both events still hold the records of k - 2 here).
+        if (k >= 2 && stage_in) HIPCHK(hipEventSynchronize(hs.ev_in));
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->s_in, hs.ev_comp, 0));
+        for (int t = 0; t < nb; ++t) {
+            float *dst = hs.d_up + (size_t)t * 9 * hw0;
+            if (stage_in) {
+                float *st = hs.h_in + (size_t)t * 9 * hw0;
+                std::vector<CopyJob> jobs;
+                for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4});
+                c->pool_in->run(jobs);
+                HIPCHK(hipMemcpyAsync(dst, st, 9 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
+            } else {
+                for (int f = 0; f < 3; ++f)
+                    HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
+            }
+        }
+        HIPCHK(hipEventRecord(hs.ev_in, c->s_in));
+        // ---- kernels: after the upload, and after download k - 2 has read this set's output buffers
+        HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_in, 0));
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_out, 0));
+        // ColorNormalize, then image.scale to the /64 size (:50-71); without a rescale the raw planes go to the
+        // network as they are and the first conv kernel normalizes on the fly
+        if (!same) HIPCHK(launch_image_scale(hs.d_up, 1, (long)nb * 9, H0, W0, hs.d_tmp, hs.d_in, fh, fw, c->stream));
+        CHK(b2f_forward_device(c, hs.d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, nb, fh, fw, hs.d_flow, nullptr, hs.d_est3, c->stream));
+        HIPCHK(launch_postprocess(hs.d_flow, hs.d_est3, C3, nb, fh, fw, H0, W0, hs.d_oflow, hs.d_fo, hs.d_bo, c->stream));
+        HIPCHK(hipEventRecord(hs.ev_comp, c->stream));
+        // ---- download: the set's pinned output buffers must have been handed over (k - 2 drained)
+        if (k >= 2 && stage_out) {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return drained >= k - 1 || abort; });
+            if (abort) return fail(drain_err);
+        }
+        HIPCHK(hipStreamWaitEvent(c->s_out, hs.ev_comp, 0));
+        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_oflow : flow + b0 * 2 * hw0, hs.d_oflow, (size_t)nb * 2 * hw0 * 8, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_fo : fwd_occ + b0 * hw0, hs.d_fo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_bo : bwd_occ + b0 * hw0, hs.d_bo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipEventRecord(hs.ev_out, c->s_out));
+        {
+            std::lock_guard<std::mutex> l(mu);
+            submitted = k + 1;
+        }
+        cv.notify_all();
+        return 0;
+    };
     int rc = 0;
-    std::vector<float> h_flow((size_t)n * 2 * hw), h_est3((size_t)n * C3 * hw);
-    do {
-        if (hipMemcpyAsync(d_in, stage.data(), stage.size() * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail("H2D copy failed"); break; }
-        rc = b2f_forward_device(c, d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, n, fh, fw, d_flow, nullptr, d_est3, c->stream);
-        if (rc) break;
-        if (hipMemcpyAsync(h_flow.data(), d_flow, h_flow.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h_est3.data(), d_est3, h_est3.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(std::string("D2H copy failed: ") + hipGetErrorString(hipGetLastError())); break; }
-    } while (0);
-    (void)hipFree(d_in); (void)hipFree(d_flow); (void)hipFree(d_est3);
-    if (rc) return rc;
-    for (int b = 0; b < n; ++b)
-        postprocess(h_flow.data() + (size_t)b * 2 * hw, h_est3.data() + (size_t)b * C3 * hw, C3, fh, fw, H0, W0,
-                    flow + (size_t)b * 2 * hw0, fwd_occ + (size_t)b * hw0, bwd_occ + (size_t)b * hw0);
+    for (int k = 0; k < nsub && !rc; ++k) rc = submit(k);
+    std::string msg = rc ? g_err : std::string();
+    if (rc) {
+        std::lock_guard<std::mutex> l(mu);
+        abort = true;
+    }
+    cv.notify_all();
+    if (drainer.joinable()) drainer.join();
+    if (!rc && abort) { rc = 1; msg = drain_err; }
+    // nothing of this call may still be in flight when the caller gets its buffers back
+    for (hipStream_t st : {c->s_in, c->stream, c->s_out}) {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess && !rc) { rc = 1; msg = std::string("b2f_compute_flow: ") + hipGetErrorString(e); }
+    }
+    if (rc) {
+        (void)hipGetLastError();
+        return fail(msg);
+    }
     return 0;
 }
 
@@ -977,6 +1249,21 @@ int b2f_op_warp_bhwd(b2f_ctx *c, const float *img, const float *grid, int B, int
     HIPCHK(launch_warp_nhwc(di.p, (long)((size_t)ih * iw * C), C, C, ih, iw, dg.p, 1.0f, B, gh, gw, dout.p, C, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, dout.p, no * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int b2f_op_image_scale(b2f_ctx *c, const float *src, int C, int Hs, int Ws, int normalize, float *dst, int Hd, int Wd)
+{
+    if (!c || !src || !dst) return fail("b2f_op_image_scale: null argument");
+    if (C <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return fail("b2f_op_image_scale: bad shape");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf ds, dt, dd;
+    const size_t ns = (size_t)C * Hs * Ws, nt = (size_t)C * Hs * Wd, nd = (size_t)C * Hd * Wd;
+    CHK(ds.alloc(ns)); CHK(dt.alloc(nt)); CHK(dd.alloc(nd));
+    HIPCHK(hipMemcpy(ds.p, src, ns * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_image_scale(ds.p, normalize, C, Hs, Ws, dt.p, dd.p, Hd, Wd, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dst, dd.p, nd * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -1,6 +1,6 @@
-// Host-side pieces of the computeFlow boundary: the deterministic weight initialiser,
-// the canonical weight layout, and the CPU pre/post-processing that back2future.lua does
-// around model:forward (image.scale, nearest rescale, thresholds).  No GPU code here.
+// Host-side pieces of the computeFlow boundary: the deterministic weight initialiser and
+// the canonical weight layout.  No GPU code here (the pre/post-processing that back2future.lua
+// does around model:forward runs on the device, b2f_boundary.hip).
 #include "b2f_host.h"
 
 #include <cmath>
@@ -70,77 +70,6 @@ void random_weights(unsigned long long seed, bool past_flow, float gain, float *
             const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
             const float t = 2.0f * u - 1.0f;
             out[d.w_off + i] = t * s;
-        }
-    }
-}
-
-// ---- image.scale(src, W, H) 'bilinear' [3P torch/image scaleLinear_rowcol]; called at
-// back2future.lua:71 to shrink the input to multiples of 64.  Separable, float intermediates;
-// up = align-corners lerp (last sample copied), down = fractional box average. ----
-static void scale_line(const float *src, long sstride, long slen, float *dst, long dstride, long dlen)
-{
-    if (dlen > slen) {
-        const float scale = (float)(slen - 1) / (float)(dlen - 1);
-        for (long di = 0; di < dlen - 1; ++di) {
-            if (slen == 1) { dst[di * dstride] = src[0]; continue; }
-            float f = di * scale;
-            const long i0 = (long)f;
-            f -= i0;
-            dst[di * dstride] = (1 - f) * src[i0 * sstride] + f * src[(i0 + 1) * sstride];
-        }
-        dst[(dlen - 1) * dstride] = src[(slen - 1) * sstride];
-    } else if (dlen < slen) {
-        const float scale = (float)slen / (float)dlen;
-        long a_i = 0;
-        float a_f = 0;
-        for (long di = 0; di < dlen; ++di) {
-            float e_f = (di + 1) * scale;
-            const long e_i = (long)e_f;
-            e_f -= e_i;
-            float acc = (1 - a_f) * src[a_i * sstride], wsum = 1 - a_f;
-            for (long si = a_i + 1; si < e_i; ++si) { acc += src[si * sstride]; wsum += 1; }
-            if (e_i < slen) { acc += e_f * src[e_i * sstride]; wsum += e_f; }
-            dst[di * dstride] = acc / wsum;
-            a_i = e_i;
-            a_f = e_f;
-        }
-    } else {
-        for (long i = 0; i < dlen; ++i) dst[i * dstride] = src[i * sstride];
-    }
-}
-
-void image_scale_bilinear(const float *src, int C, int Hs, int Ws, float *dst, int Hd, int Wd)
-{
-    std::vector<float> tmp((size_t)Hs * Wd);
-    for (int c = 0; c < C; ++c) {
-        const float *s = src + (size_t)c * Hs * Ws;
-        float *d = dst + (size_t)c * Hd * Wd;
-        for (int y = 0; y < Hs; ++y) scale_line(s + (size_t)y * Ws, 1, Ws, tmp.data() + (size_t)y * Wd, 1, Wd);
-        for (int x = 0; x < Wd; ++x) scale_line(tmp.data() + x, Wd, Hs, d + x, Wd, Hd);
-    }
-}
-
-// ---- computeFlow post-processing, back2future.lua:77-93 ----
-void postprocess(const float *flow_net, const float *est3, int est3_ch, int fh, int fw, int H0, int W0,
-                 double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
-{
-    // image.scale(..., 'simple') [3P]: src index = (long)(dst * (float)src_len / dst_len), clamped
-    const float scx = (float)fw / (float)W0, scy = (float)fh / (float)H0;
-    const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;   // :78-79
-    const size_t hw = (size_t)fh * fw, hw0 = (size_t)H0 * W0;
-    (void)est3_ch;
-    for (int j = 0; j < H0; ++j) {
-        long jj = (long)((float)j * scy);
-        if (jj > fh - 1) jj = fh - 1;
-        for (int i = 0; i < W0; ++i) {
-            long ii = (long)((float)i * scx);
-            if (ii > fw - 1) ii = fw - 1;
-            const size_t s = (size_t)jj * fw + ii, d = (size_t)j * W0 + i;
-            flow[d] = (double)flow_net[s] * sc_w;              // flow_est[1] * sc_w  (:84)
-            flow[hw0 + d] = (double)flow_net[hw + s] * sc_h;   // flow_est[2] * sc_h  (:83)
-            // occ_est = est[3]; fwd = ge(occ_est[2], 0.6666), bwd = ge(occ_est[1], 0.6666)  (:87-91)
-            fwd_occ[d] = ((double)est3[hw + s] >= 0.6666) ? 1 : 0;
-            bwd_occ[d] = ((double)est3[s] >= 0.6666) ? 1 : 0;
         }
     }
 }

@@ -1,5 +1,5 @@
 // Host-only helpers shared by the C-ABI layer: canonical weight layout, deterministic
-// init, the CPU pre/post-processing of back2future.lua:47-95, the .t7 reader.
+// init, the .t7 reader.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -24,10 +24,6 @@ struct ConvDesc {
 std::vector<ConvDesc> weight_layout(bool past_flow, long long *total);
 long long param_count(bool past_flow);
 void random_weights(unsigned long long seed, bool past_flow, float gain, float *out);
-
-void image_scale_bilinear(const float *src, int C, int Hs, int Ws, float *dst, int Hd, int Wd);
-void postprocess(const float *flow_net, const float *est3, int est3_ch, int fh, int fw, int H0, int W0,
-                 double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
 
 // .t7 reader (b2f_t7.cpp): returns false and fills err on failure.
 bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow, std::string &err);

@@ -158,4 +158,13 @@ hipError_t launch_planar_to_nhwc(const float *in, int C, int B, int h, int w, fl
                                  int pix_stride, hipStream_t s);
 hipError_t launch_fill(float *p, size_t n, float v, hipStream_t s);
 
+// ---- computeFlow boundary on the device (b2f_boundary.hip) ----------------------------------
+// image.scale 'bilinear' of `planes` planes Hs x Ws -> Hd x Wd (tmp: planes x Hs x Wd floats), optionally with
+// ColorNormalize applied to the source samples (plane % 3 = colour); bit-identical to the host function
+hipError_t launch_image_scale(const float *src, int normalize, long planes, int Hs, int Ws, float *tmp, float *dst,
+                              int Hd, int Wd, hipStream_t s);
+// nearest rescale + sc_w / sc_h + thresholds (back2future.lua:77-93): planar net outputs -> f64 flow, u8 masks
+hipError_t launch_postprocess(const float *flow_net, const float *est3, int est3_ch, int B, int fh, int fw, int H0, int W0,
+                              double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ, hipStream_t s);
+
 }  // namespace b2f

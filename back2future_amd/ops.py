@@ -58,3 +58,12 @@ def upsample_flow2x(model, x):
     y = np.empty((B, 2, 2 * h, 2 * w), np.float32)
     _lib.check(_lib.lib().b2f_op_upsample_flow2x(_h(model), _lib.fptr(x), B, h, w, _lib.fptr(y)))
     return y
+
+
+def image_scale(model, src, Hd, Wd, normalize=False):
+    """image.scale(src, Wd, Hd) 'bilinear' (back2future.lua:71) on C x Hs x Ws, optionally after ColorNormalize."""
+    src = _lib.f32(src)
+    Cc, Hs, Ws = src.shape
+    dst = np.empty((Cc, Hd, Wd), np.float32)
+    _lib.check(_lib.lib().b2f_op_image_scale(_h(model), _lib.fptr(src), Cc, Hs, Ws, int(normalize), _lib.fptr(dst), Hd, Wd))
+    return dst

@@ -148,6 +148,11 @@ B2F_API int b2f_op_conv3x3(b2f_ctx *ctx, const float *x, int B, int Ci, int H, i
 /* nn.SpatialUpSamplingBilinear(2) on a 2-channel flow field -- pwc.lua:360-381;
  * x: B x 2 x h x w -> y: B x 2 x 2h x 2w.                                            */
 B2F_API int b2f_op_upsample_flow2x(b2f_ctx *ctx, const float *x, int B, int h, int w, float *y);
+/* image.scale(src, Wd, Hd) 'bilinear' [torch/image] as computeFlow uses it -- back2future.lua:71 -- with
+ * ColorNormalize (transforms.lua:33-45, plane % 3 = colour) applied first when normalize != 0;
+ * src: C x Hs x Ws -> dst: C x Hd x Wd.  Bit-identical to the CPU routine.             */
+B2F_API int b2f_op_image_scale(b2f_ctx *ctx, const float *src, int C, int Hs, int Ws, int normalize,
+                       float *dst, int Hd, int Wd);
 
 #ifdef __cplusplus
 }

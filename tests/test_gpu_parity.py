@@ -200,6 +200,67 @@ def test_compute_flow_non_multiple_of_64(soft):
     assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
 
 
+@pytest.mark.parametrize("Hs,Ws,Hd,Wd", [(150, 200, 128, 192), (375, 1242, 320, 1216), (70, 64, 64, 64), (64, 90, 64, 64),
+                                         (40, 50, 64, 80), (33, 1, 48, 5), (64, 64, 64, 64), (97, 131, 13, 17)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_image_scale_bit_exact(hard, Hs, Ws, Hd, Wd, normalize):
+    """image.scale 'bilinear' (+ ColorNormalize) on the device vs the CPU routine: same IEEE operations in the
+    same order, so not one bit may differ (down, up, mixed and identity axes)."""
+    r = _rng(Hs * 7 + Wd)
+    src = r.random((9, Hs, Ws)).astype(np.float32)
+    exp = O.image_scale_bilinear(O.color_normalize(src) if normalize else src, Hd, Wd)
+    got = ops.image_scale(hard, src, Hd, Wd, normalize)
+    np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("which,H0,W0", [("soft", 150, 200), ("hard", 131, 259)])
+def test_compute_flow_boundary_bit_exact(hard, soft, which, H0, W0):
+    """The device pre/post-processing of computeFlow (back2future.lua:48-93) around the network: feed model:forward
+    the CPU-prepared input, post-process its est[1] / est[3] on the CPU, and require computeFlow's results to be
+    bit-identical (flow in f64, masks)."""
+    m = hard if which == "hard" else soft
+    r = _rng(H0 + W0)
+    ims = _triplet(r, H0, W0)
+    fh, fw = H0 - H0 % 64, W0 - W0 % 64
+    x = O.image_scale_bilinear(O.color_normalize(np.concatenate(ims, 0)), fh, fw)[None]
+    outs = m.forward(x)
+    fnet, est3 = outs[0][0].astype(np.float64), outs[2][0].astype(np.float64)
+    eflow = O.image_scale_simple(fnet, H0, W0)
+    eflow[0] *= float(W0) / float(fw)
+    eflow[1] *= float(H0) / float(fh)
+    eocc = O.image_scale_simple(est3, H0, W0)
+    flow, fo, bo = m.computeFlow(*ims)
+    np.testing.assert_array_equal(flow, eflow)
+    np.testing.assert_array_equal(fo[0], (eocc[1] >= 0.6666).astype(np.uint8))
+    np.testing.assert_array_equal(bo[0], (eocc[0] >= 0.6666).astype(np.uint8))
+
+
+def test_host_pipeline_many_sub_batches(soft, monkeypatch):
+    """b2f_compute_flow_batch cut into one-triplet sub-batches (5 of them through the two buffer sets, pageable
+    and page-locked caller buffers): every triplet must equal its stand-alone computeFlow bit for bit."""
+    import torch
+    r = _rng(31)
+    H0, W0, n = 70, 140, 5
+    trip = [_triplet(r, H0, W0) for _ in range(n)]
+    im = [np.stack([t[i] for t in trip]) for i in range(3)]
+    single = [soft.computeFlow(*t) for t in trip]
+    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(H0 * W0))
+    monkeypatch.setenv("B2F_HOST_THREADS", "3")
+    res = [soft.computeFlowBatch(*im)]
+    pin_in = [torch.from_numpy(a).pin_memory() for a in im]
+    pin_out = (torch.empty((n, 2, H0, W0), dtype=torch.float64).pin_memory(),
+               torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory(),
+               torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory())
+    res.append(soft.computeFlowBatch(*[t.numpy() for t in pin_in], out=tuple(t.numpy() for t in pin_out)))
+    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(2 * H0 * W0))      # 2 + 2 + 1
+    res.append(soft.computeFlowBatch(*im))
+    for fb, fob, bob in res:
+        for i in range(n):
+            np.testing.assert_array_equal(fb[i], single[i][0])
+            np.testing.assert_array_equal(fob[i], single[i][1])
+            np.testing.assert_array_equal(bob[i], single[i][2])
+
+
 def test_batch_equals_single(soft):
     r = _rng(9)
     trip = [_triplet(r, 64, 128) for _ in range(3)]
