@@ -76,26 +76,67 @@ struct GraphKey {
 struct HostSlot {
     char *dev = nullptr;        // device blob, carved below
     size_t dev_bytes = 0;
-    char *pin = nullptr;        // pinned staging blob (only touched when the caller's buffers are pageable)
+    char *pin = nullptr;        // pinned staging blob
     size_t pin_bytes = 0;
+    unsigned char *d_u8 = nullptr;   // 8-bit transport of the input planes (see pack_u8_piece)
     float *d_up = nullptr, *d_tmp = nullptr, *d_in = nullptr, *d_flow = nullptr, *d_est3 = nullptr;
-    double *d_oflow = nullptr;
+    float *d_flow32 = nullptr;       // flow at H0 x W0 (fp32, before the f64 sc_w / sc_h factors); = d_flow without a rescale
     unsigned char *d_fo = nullptr, *d_bo = nullptr;
-    float *h_in = nullptr;
-    double *h_oflow = nullptr;
+    unsigned char *h_u8 = nullptr;
+    float *h_in = nullptr, *h_flow32 = nullptr;
     unsigned char *h_fo = nullptr, *h_bo = nullptr;
     hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
 };
 
+// Host work items of the pipeline, cut into pieces and spread over a pool of threads.
+enum { JOB_COPY = 0, JOB_F32_TO_F64 = 1, JOB_PACK_U8 = 2 };
 struct CopyJob {
     void *dst;
     const void *src;
-    size_t bytes;
+    size_t bytes;                     // of the source
+    int kind = JOB_COPY;
+    double scale = 1.0;               // JOB_F32_TO_F64: dst = (double)src * scale   (back2future.lua:83-84)
+    std::atomic<int> *inexact = nullptr;   // JOB_PACK_U8: set when a value is not k / 255
 };
 
-// Persistent host threads that memcpy job lists in 1 MB pieces (the caller's thread works too).  One core moves
-// ~10 GB/s; a full-HD triplet is 71 MB in and 35 MB out, so a single-threaded staging copy would cost several
-// times the 1.5 ms the GPU needs for it.
+// 8-bit transport: image.load hands computeFlow floats that came from 8-bit files, i.e. k / 255.  Such a plane
+// crosses the link as bytes (a quarter of the traffic of a path that is PCIe-bound) and is rebuilt on the device
+// by the same correctly rounded division, but only if that reproduces every float of it bit for bit; one other
+// value (or -0, NaN, ...) and the triplet is uploaded as floats instead.
+inline bool pack_u8_piece(unsigned char *d, const float *s, size_t n)
+{
+    uint32_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = s[i];
+        int k = (int)(v * 255.0f + 0.5f);
+        k = k < 0 ? 0 : (k > 255 ? 255 : k);
+        const float r = (float)k / 255.0f;
+        uint32_t vb, rb;
+        memcpy(&vb, &v, 4);
+        memcpy(&rb, &r, 4);
+        bad |= vb ^ rb;
+        d[i] = (unsigned char)k;
+    }
+    return bad == 0;
+}
+
+inline void run_piece(const CopyJob &j)
+{
+    if (j.kind == JOB_COPY) {
+        memcpy(j.dst, j.src, j.bytes);
+    } else if (j.kind == JOB_F32_TO_F64) {
+        const float *s = (const float *)j.src;
+        double *d = (double *)j.dst;
+        const double sc = j.scale;
+        for (size_t i = 0, n = j.bytes / 4; i < n; ++i) d[i] = (double)s[i] * sc;
+    } else {
+        if (!pack_u8_piece((unsigned char *)j.dst, (const float *)j.src, j.bytes / 4)) j.inexact->store(1, std::memory_order_relaxed);
+    }
+}
+
+// Persistent host threads that execute job lists in 1 MB pieces (the caller's thread works too).  One core moves
+// ~10 GB/s; a full-HD triplet is 71 MB in and 35 MB out, so single-threaded staging would cost several times the
+// 1.5 ms the GPU needs for it.
 class CopyPool {
 public:
     explicit CopyPool(int workers)
@@ -118,12 +159,18 @@ public:
         std::vector<CopyJob> pieces;
         size_t bytes = 0;
         for (const CopyJob &j : jobs) {
-            for (size_t o = 0; o < j.bytes; o += kPiece)
-                pieces.push_back({(char *)j.dst + o, (const char *)j.src + o, std::min(kPiece, j.bytes - o)});
+            const size_t dmul = j.kind == JOB_F32_TO_F64 ? 2 : 1, ddiv = j.kind == JOB_PACK_U8 ? 4 : 1;
+            for (size_t o = 0; o < j.bytes; o += kPiece) {
+                CopyJob q = j;
+                q.dst = (char *)j.dst + o * dmul / ddiv;
+                q.src = (const char *)j.src + o;
+                q.bytes = std::min(kPiece, j.bytes - o);
+                pieces.push_back(q);
+            }
             bytes += j.bytes;
         }
         if (th_.empty() || bytes < (2u << 20)) {
-            for (const CopyJob &j : pieces) memcpy(j.dst, j.src, j.bytes);
+            for (const CopyJob &j : pieces) run_piece(j);
             return;
         }
         std::unique_lock<std::mutex> l(m_);
@@ -133,7 +180,7 @@ public:
         while (next_ < pieces.size()) {
             const CopyJob j = pieces[next_++];
             l.unlock();
-            memcpy(j.dst, j.src, j.bytes);
+            run_piece(j);
             l.lock();
             ++done_;
         }
@@ -150,7 +197,7 @@ private:
             if (stop_) return;
             const CopyJob j = (*pieces_)[next_++];
             l.unlock();
-            memcpy(j.dst, j.src, j.bytes);
+            run_piece(j);
             l.lock();
             if (++done_ == pieces_->size()) cv_done_.notify_all();
         }
@@ -961,13 +1008,13 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // carve the slot's device and pinned blobs for sub-batches of up to SB triplets; grows (never shrinks) the blobs
 int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0, int fw, bool same, int C3, bool stage_in,
-                bool stage_out)
+                bool stage_masks, bool use_u8)
 {
-    const size_t n_up = align256((size_t)SB * 9 * hw0 * 4), n_in = same ? 0 : align256((size_t)SB * 9 * hw * 4),
-                 n_tmp = same ? 0 : align256((size_t)SB * 9 * H0 * fw * 4), n_flow = align256((size_t)SB * 2 * hw * 4),
-                 n_est3 = align256((size_t)SB * C3 * hw * 4), n_of = align256((size_t)SB * 2 * hw0 * 8),
-                 n_occ = align256((size_t)SB * hw0);
-    const size_t need_dev = n_up + n_in + n_tmp + n_flow + n_est3 + n_of + 2 * n_occ;
+    const size_t n_up = align256((size_t)SB * 9 * hw0 * 4), n_u8 = use_u8 ? align256((size_t)SB * 9 * hw0) : 0,
+                 n_in = same ? 0 : align256((size_t)SB * 9 * hw * 4), n_tmp = same ? 0 : align256((size_t)SB * 9 * H0 * fw * 4),
+                 n_flow = align256((size_t)SB * 2 * hw * 4), n_est3 = align256((size_t)SB * C3 * hw * 4),
+                 n_f32 = align256((size_t)SB * 2 * hw0 * 4), n_occ = align256((size_t)SB * hw0);
+    const size_t need_dev = n_up + n_u8 + n_in + n_tmp + n_flow + n_est3 + (same ? 0 : n_f32) + 2 * n_occ;
     if (need_dev > hs.dev_bytes) {
         if (hs.dev) {
             HIPCHK(hipDeviceSynchronize());
@@ -981,14 +1028,15 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
     }
     char *d = hs.dev;
     hs.d_up = (float *)d; d += n_up;
+    hs.d_u8 = (unsigned char *)d; d += n_u8;
     hs.d_in = same ? hs.d_up : (float *)d; d += n_in;
     hs.d_tmp = (float *)d; d += n_tmp;
     hs.d_flow = (float *)d; d += n_flow;
     hs.d_est3 = (float *)d; d += n_est3;
-    hs.d_oflow = (double *)d; d += n_of;
+    hs.d_flow32 = same ? hs.d_flow : (float *)d; d += same ? 0 : n_f32;
     hs.d_fo = (unsigned char *)d; d += n_occ;
     hs.d_bo = (unsigned char *)d;
-    const size_t need_pin = (stage_in ? n_up : 0) + (stage_out ? n_of + 2 * n_occ : 0);
+    const size_t need_pin = (stage_in ? n_up : 0) + n_u8 + n_f32 + (stage_masks ? 2 * n_occ : 0);
     if (need_pin > hs.pin_bytes) {
         if (hs.pin) {
             HIPCHK(hipDeviceSynchronize());
@@ -1000,8 +1048,9 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
     }
     char *h = hs.pin;
     hs.h_in = (float *)h; h += stage_in ? n_up : 0;
-    hs.h_oflow = (double *)h; h += stage_out ? n_of : 0;
-    hs.h_fo = (unsigned char *)h; h += stage_out ? n_occ : 0;
+    hs.h_u8 = (unsigned char *)h; h += n_u8;
+    hs.h_flow32 = (float *)h; h += n_f32;
+    hs.h_fo = (unsigned char *)h; h += stage_masks ? n_occ : 0;
     hs.h_bo = (unsigned char *)h;
     for (hipEvent_t *e : {&hs.ev_in, &hs.ev_comp, &hs.ev_out})
         if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1010,14 +1059,17 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
 
 }  // namespace
 
-// The n triplets are cut into sub-batches (B2F_HOST_SUBBATCH_PIXELS input pixels each, default 8 Mpx = four
+// The n triplets are cut into sub-batches (up to B2F_HOST_SUBBATCH_PIXELS input pixels each, default 16 Mpx = eight
 // full-HD triplets) that flow through two buffer sets on three streams: uploads on s_in, ColorNormalize /
 // image.scale / the network / the nearest rescale + thresholds on the context's stream, downloads on s_out.
 // A buffer set's input half is reused as soon as the kernels that read it are done and its output half as soon
-// as its download has been handed over, so in steady state all three streams are busy.  Host threads only copy
-// between the caller's buffers and the pinned sets (B2F_HOST_THREADS, default 16, two thirds of them on the
-// input side; the output side is drained by a second control thread) -- and not even that when the caller's
-// buffers are already page-locked.
+// as its download has been handed over, so in steady state all three streams are busy.
+// The link is the bound of this entry point (one MI355X box: 56 GB/s in either direction, but only 55 GB/s for
+// both together), so both directions carry as few bytes as exactness allows: inputs that are k / 255 go up as
+// bytes (pack_u8_piece), the flow comes down as the network's fp32 values and becomes `double * sc` on the host
+// (back2future.lua:80-84), exactly the reference's arithmetic.  Host threads (B2F_HOST_THREADS, default 16, two
+// thirds on the input side; the output side is driven by a second control thread) do the packing / staging and
+// the f32 -> f64 conversion; page-locked caller buffers are DMA'd in place where no conversion is involved.
 int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
                            int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
 {
@@ -1030,30 +1082,40 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
     const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
     const bool same = (fw == W0 && fh == H0);
     const int C3 = c->past_flow ? 2 : 3;
-    const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (8ll << 20);
+    const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;   // :78-79
+    const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (16ll << 20);
     const int nthreads = std::max(2, getenv("B2F_HOST_THREADS") ? atoi(getenv("B2F_HOST_THREADS"))
                                                                  : (int)std::min(16u, std::thread::hardware_concurrency()));
+    const bool use_u8 = !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
     const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
-    const int nsub = (n + SB - 1) / SB;
+    // sub-batch sizes ramp up 1, 2, 4, ... SB: the kernels start after one triplet's upload instead of SB of them
+    // (B2F_HOST_RAMP=0: uniform sizes)
+    const bool ramp = !(getenv("B2F_HOST_RAMP") && atoi(getenv("B2F_HOST_RAMP")) == 0);
+    std::vector<std::pair<size_t, int>> subs;   // (first triplet, count)
+    for (int b0 = 0, sz = ramp ? 1 : SB; b0 < n; sz = std::min(2 * sz, SB)) {
+        const int nb = std::min(sz, n - b0);
+        subs.push_back({(size_t)b0, nb});
+        b0 += nb;
+    }
+    const int nsub = (int)subs.size();
 
     if (!c->s_in) HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     if (!c->s_out) HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
     const bool stage_in = !(is_pinned(im1, (size_t)n * 3 * hw0 * 4) && is_pinned(im2, (size_t)n * 3 * hw0 * 4) &&
                             is_pinned(im3, (size_t)n * 3 * hw0 * 4));
-    const bool stage_out = !(is_pinned(flow, (size_t)n * 2 * hw0 * 8) && is_pinned(fwd_occ, (size_t)n * hw0) &&
-                             is_pinned(bwd_occ, (size_t)n * hw0));
+    const bool stage_masks = !(is_pinned(fwd_occ, (size_t)n * hw0) && is_pinned(bwd_occ, (size_t)n * hw0));
     for (int k = 0; k < std::min(nsub, 2); ++k)
-        CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_out));
-    // the calling thread and the drain thread each count as one copier of their pool
+        CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_masks, use_u8));
+    // the calling thread and the drain thread each count as one worker of their pool
     const int w_out = std::max(0, nthreads / 3 - 1), w_in = std::max(0, nthreads - nthreads / 3 - 1);
-    if (stage_in && (!c->pool_in || c->pool_in->workers() != w_in)) c->pool_in.reset(new CopyPool(w_in));
-    if (stage_out && (!c->pool_out || c->pool_out->workers() != w_out)) c->pool_out.reset(new CopyPool(w_out));
+    if (!c->pool_in || c->pool_in->workers() != w_in) c->pool_in.reset(new CopyPool(w_in));
+    if (!c->pool_out || c->pool_out->workers() != w_out) c->pool_out.reset(new CopyPool(w_out));
 
     const float *ims[3] = {im1, im2, im3};
     // ---- output side: a second control thread hands finished downloads to the caller ----
     std::mutex mu;
     std::condition_variable cv;
-    int submitted = 0, drained = 0;   // sub-batches whose downloads are enqueued / copied out (guarded by mu)
+    int submitted = 0, drained = 0;   // sub-batches whose downloads are enqueued / handed over (guarded by mu)
     bool abort = false;
     std::string drain_err;
     auto drain_loop = [&]() {
@@ -1067,10 +1129,18 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
             HostSlot &hs = c->slot[k & 1];
             const hipError_t e = hipEventSynchronize(hs.ev_out);
             if (e == hipSuccess) {
-                const size_t b0 = (size_t)k * SB, nb = std::min<size_t>(SB, n - b0);
-                c->pool_out->run({{flow + b0 * 2 * hw0, hs.h_oflow, nb * 2 * hw0 * 8},
-                                  {fwd_occ + b0 * hw0, hs.h_fo, nb * hw0},
-                                  {bwd_occ + b0 * hw0, hs.h_bo, nb * hw0}});
+                const size_t b0 = subs[k].first, nb = (size_t)subs[k].second;
+                std::vector<CopyJob> jobs;
+                // flow_est[1] * sc_w, flow_est[2] * sc_h on the :double() copy of est[1] (:80-84)
+                for (size_t t = 0; t < nb; ++t)
+                    for (int ch = 0; ch < 2; ++ch)
+                        jobs.push_back({flow + ((b0 + t) * 2 + ch) * hw0, hs.h_flow32 + (t * 2 + ch) * hw0, hw0 * 4, JOB_F32_TO_F64,
+                                        ch == 0 ? sc_w : sc_h, nullptr});
+                if (stage_masks) {
+                    jobs.push_back({fwd_occ + b0 * hw0, hs.h_fo, nb * hw0});
+                    jobs.push_back({bwd_occ + b0 * hw0, hs.h_bo, nb * hw0});
+                }
+                c->pool_out->run(jobs);
             }
             std::lock_guard<std::mutex> l(mu);
             if (e != hipSuccess) {
@@ -1082,20 +1152,35 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
             if (abort) return;
         }
     };
-    std::thread drainer;
-    if (stage_out) drainer = std::thread(drain_loop);
+    std::thread drainer(drain_loop);
 
+    bool try_u8 = use_u8;             // off for the rest of the call after the first triplet that is not 8-bit data
+    std::atomic<int> inexact{0};
     auto submit = [&](int k) -> int {
         HostSlot &hs = c->slot[k & 1];
-        const size_t b0 = (size_t)k * SB;
-        const int nb = (int)std::min<size_t>(SB, n - b0);
+        const size_t b0 = subs[k].first;
+        const int nb = subs[k].second;
         // ---- upload: torch.cat({im1, im2, im3}, 1) (back2future.lua:48) = [triplet][frame][3][H0][W0] on the device.
-        // The set's staging buffer is free once upload k - 2 has left it, its device buffer once the kernels of
-        // k - 2 are done (both events still hold the records of k - 2 here).
-        if (k >= 2 && stage_in) HIPCHK(hipEventSynchronize(hs.ev_in));
+        // The set's staging buffers are free once upload k - 2 has left them, its device buffers once the kernels
+        // of k - 2 are done (both events still hold the records of k - 2 here).
+        if (k >= 2) HIPCHK(hipEventSynchronize(hs.ev_in));
         if (k >= 2) HIPCHK(hipStreamWaitEvent(c->s_in, hs.ev_comp, 0));
+        std::vector<int> as_u8(nb, 0);
         for (int t = 0; t < nb; ++t) {
             float *dst = hs.d_up + (size_t)t * 9 * hw0;
+            if (try_u8) {
+                unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
+                std::vector<CopyJob> jobs;
+                for (int f = 0; f < 3; ++f)
+                    jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact});
+                c->pool_in->run(jobs);
+                if (!inexact.load()) {
+                    HIPCHK(hipMemcpyAsync(hs.d_u8 + (size_t)t * 9 * hw0, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
+                    as_u8[t] = 1;
+                    continue;
+                }
+                try_u8 = false;
+            }
             if (stage_in) {
                 float *st = hs.h_in + (size_t)t * 9 * hw0;
                 std::vector<CopyJob> jobs;
@@ -1111,22 +1196,24 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
         // ---- kernels: after the upload, and after download k - 2 has read this set's output buffers
         HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_in, 0));
         if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_out, 0));
+        for (int t = 0; t < nb; ++t)
+            if (as_u8[t]) HIPCHK(launch_unpack_u8(hs.d_u8 + (size_t)t * 9 * hw0, 9 * hw0, hs.d_up + (size_t)t * 9 * hw0, c->stream));
         // ColorNormalize, then image.scale to the /64 size (:50-71); without a rescale the raw planes go to the
         // network as they are and the first conv kernel normalizes on the fly
         if (!same) HIPCHK(launch_image_scale(hs.d_up, 1, (long)nb * 9, H0, W0, hs.d_tmp, hs.d_in, fh, fw, c->stream));
         CHK(b2f_forward_device(c, hs.d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, nb, fh, fw, hs.d_flow, nullptr, hs.d_est3, c->stream));
-        HIPCHK(launch_postprocess(hs.d_flow, hs.d_est3, C3, nb, fh, fw, H0, W0, hs.d_oflow, hs.d_fo, hs.d_bo, c->stream));
+        HIPCHK(launch_postprocess(hs.d_flow, hs.d_est3, C3, nb, fh, fw, H0, W0, same ? nullptr : hs.d_flow32, hs.d_fo, hs.d_bo, c->stream));
         HIPCHK(hipEventRecord(hs.ev_comp, c->stream));
         // ---- download: the set's pinned output buffers must have been handed over (k - 2 drained)
-        if (k >= 2 && stage_out) {
+        if (k >= 2) {
             std::unique_lock<std::mutex> l(mu);
             cv.wait(l, [&] { return drained >= k - 1 || abort; });
             if (abort) return fail(drain_err);
         }
         HIPCHK(hipStreamWaitEvent(c->s_out, hs.ev_comp, 0));
-        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_oflow : flow + b0 * 2 * hw0, hs.d_oflow, (size_t)nb * 2 * hw0 * 8, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_fo : fwd_occ + b0 * hw0, hs.d_fo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(stage_out ? hs.h_bo : bwd_occ + b0 * hw0, hs.d_bo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipMemcpyAsync(hs.h_flow32, hs.d_flow32, (size_t)nb * 2 * hw0 * 4, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipMemcpyAsync(stage_masks ? hs.h_fo : fwd_occ + b0 * hw0, hs.d_fo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipMemcpyAsync(stage_masks ? hs.h_bo : bwd_occ + b0 * hw0, hs.d_bo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
         HIPCHK(hipEventRecord(hs.ev_out, c->s_out));
         {
             std::lock_guard<std::mutex> l(mu);
@@ -1143,7 +1230,7 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
         abort = true;
     }
     cv.notify_all();
-    if (drainer.joinable()) drainer.join();
+    drainer.join();
     if (!rc && abort) { rc = 1; msg = drain_err; }
     // nothing of this call may still be in flight when the caller gets its buffers back
     for (hipStream_t st : {c->s_in, c->stream, c->s_out}) {

@@ -1,10 +1,10 @@
 // Device side of the computeFlow boundary (/root/reference/back2future.lua:48-93): what the reference does on the
 // host around model:forward -- ColorNormalize, image.scale(..., W, H) 'bilinear' down to multiples of 64, and
-// after the forward pass image.scale(..., 'simple') back to the input size, the sc_w / sc_h factors on the
-// double-precision flow and the 0.6666 thresholds -- runs here on the uploaded planes, so the host only moves
-// bytes.  The arithmetic is the host functions' (b2f_host.cpp, oracle/b2f_oracle.c) operation for operation:
-// every output element is produced by one thread with the same sequence of IEEE fp32 / fp64 operations (the file is
-// built with -ffp-contract=off and correctly rounded division), so the results are bit-identical to the CPU ones.
+// after the forward pass image.scale(..., 'simple') back to the input size and the 0.6666 thresholds -- runs here
+// on the uploaded planes, so the host only moves bytes (and widens the flow to f64, b2f_api.hip).  The arithmetic
+// is the CPU routines' (oracle/b2f_oracle.c) operation for operation: every output element is produced by one
+// thread with the same sequence of IEEE fp32 operations (the file is built with -ffp-contract=off and correctly
+// rounded division), so the results are bit-identical to the CPU ones.
 #include "b2f_internal.h"
 
 namespace b2f {
@@ -76,11 +76,13 @@ hipError_t launch_image_scale(const float *src, int normalize, long planes, int 
     return hipGetLastError();
 }
 
-// back2future.lua:77-93: nearest rescale of flow_est and occ_est to H0 x W0, flow * (sc_w, sc_h) in double,
-// fwd_occ = ge(occ_est[2], 0.6666), bwd_occ = ge(occ_est[1], 0.6666).
-// flow_net [B][2][fh][fw], est3 [B][est3_ch][fh][fw] -> flow [B][2][H0][W0] f64, fwd/bwd [B][H0][W0] u8
+// back2future.lua:77-93: image.scale(..., 'simple') of est[1] and est[3] to H0 x W0 and the thresholds
+// fwd_occ = ge(occ_est[2], 0.6666), bwd_occ = ge(occ_est[1], 0.6666).  The flow leaves the device as the network's
+// fp32 values (its :double() copy times sc_w / sc_h is formed by the host threads that hand it to the caller:
+// half the bytes on the link); flow32 == nullptr when H0 x W0 is the network size (the flow is downloaded as is).
+// flow_net [B][2][fh][fw], est3 [B][est3_ch][fh][fw] -> flow32 [B][2][H0][W0] f32, fwd/bwd [B][H0][W0] u8
 __global__ void postprocess_kernel(const float *flow_net, const float *est3, int est3_ch, int B, int fh, int fw, int H0,
-                                   int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+                                   int W0, float *flow32, unsigned char *fwd_occ, unsigned char *bwd_occ)
 {
     const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,25 +91,47 @@ __global__ void postprocess_kernel(const float *flow_net, const float *est3, int
     const int j = (int)(d / W0), i = (int)(d - (size_t)j * W0);
     // image.scale 'simple' [3P]: src index = (long)(dst * (float)src_len / dst_len), clamped
     const float scx = (float)fw / (float)W0, scy = (float)fh / (float)H0;
-    const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;
     long jj = (long)((float)j * scy);
     if (jj > fh - 1) jj = fh - 1;
     long ii = (long)((float)i * scx);
     if (ii > fw - 1) ii = fw - 1;
     const size_t s = (size_t)jj * fw + ii;
-    const float *fn = flow_net + b * 2 * hw, *e3 = est3 + b * est3_ch * hw;
-    flow[b * 2 * hw0 + d] = (double)fn[s] * sc_w;
-    flow[b * 2 * hw0 + hw0 + d] = (double)fn[hw + s] * sc_h;
+    const float *e3 = est3 + b * est3_ch * hw;
+    if (flow32) {
+        const float *fn = flow_net + b * 2 * hw;
+        flow32[b * 2 * hw0 + d] = fn[s];
+        flow32[b * 2 * hw0 + hw0 + d] = fn[hw + s];
+    }
     fwd_occ[t] = ((double)e3[hw + s] >= 0.6666) ? 1 : 0;
     bwd_occ[t] = ((double)e3[s] >= 0.6666) ? 1 : 0;
 }
 
 hipError_t launch_postprocess(const float *flow_net, const float *est3, int est3_ch, int B, int fh, int fw, int H0, int W0,
-                              double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ, hipStream_t s)
+                              float *flow32, unsigned char *fwd_occ, unsigned char *bwd_occ, hipStream_t s)
 {
     const size_t n = (size_t)B * H0 * W0;
     hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flow_net, est3, est3_ch, B, fh,
-                       fw, H0, W0, flow, fwd_occ, bwd_occ);
+                       fw, H0, W0, flow32, fwd_occ, bwd_occ);
+    return hipGetLastError();
+}
+
+// 8-bit transport of input planes whose values are all k / 255 (b2f_api.hip:pack_u8_piece): the same correctly
+// rounded division rebuilds the caller's floats bit for bit.  n multiple of 4 not required.
+__global__ void unpack_u8_kernel(const unsigned char *in, size_t n, float *out)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n && ((uintptr_t)(in + i) & 3) == 0 && ((uintptr_t)(out + i) & 15) == 0) {
+        const uchar4 k = *reinterpret_cast<const uchar4 *>(in + i);
+        *reinterpret_cast<float4 *>(out + i) = make_float4(__fdiv_rn((float)k.x, 255.0f), __fdiv_rn((float)k.y, 255.0f),
+                                                           __fdiv_rn((float)k.z, 255.0f), __fdiv_rn((float)k.w, 255.0f));
+    } else {
+        for (size_t q = i; q < n && q < i + 4; ++q) out[q] = __fdiv_rn((float)in[q], 255.0f);
+    }
+}
+
+hipError_t launch_unpack_u8(const unsigned char *in, size_t n, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(unpack_u8_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, in, n, out);
     return hipGetLastError();
 }
 

@@ -163,8 +163,11 @@ hipError_t launch_fill(float *p, size_t n, float v, hipStream_t s);
 // ColorNormalize applied to the source samples (plane % 3 = colour); bit-identical to the host function
 hipError_t launch_image_scale(const float *src, int normalize, long planes, int Hs, int Ws, float *tmp, float *dst,
                               int Hd, int Wd, hipStream_t s);
-// nearest rescale + sc_w / sc_h + thresholds (back2future.lua:77-93): planar net outputs -> f64 flow, u8 masks
+// nearest rescale + thresholds (back2future.lua:77-93): planar net outputs -> fp32 flow at H0 x W0 (nullptr: not
+// written, the net size is the output size), u8 masks
 hipError_t launch_postprocess(const float *flow_net, const float *est3, int est3_ch, int B, int fh, int fw, int H0, int W0,
-                              double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ, hipStream_t s);
+                              float *flow32, unsigned char *fwd_occ, unsigned char *bwd_occ, hipStream_t s);
+// out[i] = in[i] / 255 (correctly rounded): device end of the 8-bit input transport
+hipError_t launch_unpack_u8(const unsigned char *in, size_t n, float *out, hipStream_t s);
 
 }  // namespace b2f

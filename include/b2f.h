@@ -94,7 +94,8 @@ B2F_API int b2f_compute_flow(b2f_ctx *ctx, const float *im1, const float *im2, c
                      unsigned char *bwd_occ);
 /* Same on n independent triplets (host buffers, n x 3 x H0 x W0 each frame set; outputs
  * n x 2 x H0 x W0 and n x H0 x W0).  The library overlaps uploads, kernels and downloads
- * of consecutive sub-batches; page-locked buffers are DMA'd in place, pageable ones staged. */
+ * of consecutive sub-batches; planes whose values are all k/255 cross the link as bytes
+ * (rebuilt bit for bit on the device), the flow as fp32 widened on the host.          */
 B2F_API int b2f_compute_flow_batch(b2f_ctx *ctx, int n, const float *im1, const float *im2,
                            const float *im3, int H0, int W0, double *flow,
                            unsigned char *fwd_occ, unsigned char *bwd_occ);

@@ -261,6 +261,29 @@ def test_host_pipeline_many_sub_batches(soft, monkeypatch):
             np.testing.assert_array_equal(bob[i], single[i][2])
 
 
+@pytest.mark.parametrize("H0,W0", [(64, 128), (67, 131)])
+def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
+    """Inputs that are k / 255 (what image.load returns for 8-bit files) cross the link as bytes and are rebuilt on
+    the device; the results must equal the float upload bit for bit -- also when a later triplet of the same call
+    is not 8-bit data and the call falls back to floats from there on."""
+    r = _rng(H0)
+    n = 5
+    q = lambda a: (np.round(a * 255.0).astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    trip = [_triplet(r, H0, W0) for _ in range(n)]
+    trip = [[q(a) for a in t] if i != 3 else t for i, t in enumerate(trip)]     # triplet 3 keeps arbitrary floats
+    im = [np.stack([t[i] for t in trip]) for i in range(3)]
+    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(2 * H0 * W0))
+    monkeypatch.setenv("B2F_HOST_U8", "0")
+    ref = hard.computeFlowBatch(*im)
+    ref4 = hard.computeFlowBatch(*[a[:3] for a in im])
+    monkeypatch.setenv("B2F_HOST_U8", "1")
+    got = hard.computeFlowBatch(*im)
+    got4 = hard.computeFlowBatch(*[a[:3] for a in im])                          # all three triplets go as bytes
+    for a, b in zip(ref + ref4, got + got4):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(ref[0]).max() > 0
+
+
 def test_batch_equals_single(soft):
     r = _rng(9)
     trip = [_triplet(r, 64, 128) for _ in range(3)]

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--u8", type=int, default=0, help="1: inputs are k / 255 (8-bit image data), eligible for the byte transport")
     ap.add_argument("--drop-symbol", action="append", default=[], help="for A/B runs against an older B2F_LIB build")
     a = ap.parse_args()
     from back2future_amd import _lib
@@ -32,7 +33,9 @@ def main():
     m = back2future.Model("random:soft:5:2.0")
     g = torch.Generator().manual_seed(1)
     ims = [torch.rand((n, 3, H, W), generator=g) for _ in range(3)]
-    res = {"n": n, "H": H, "W": W, "env": {k: v for k, v in os.environ.items() if k.startswith("B2F_")}}
+    if a.u8:
+        ims = [torch.round(t * 255.0) / 255.0 for t in ims]
+    res = {"n": n, "H": H, "W": W, "u8_data": a.u8, "env": {k: v for k, v in os.environ.items() if k.startswith("B2F_")}}
 
     def timed(fn):
         fn()                                   # buffers, graphs, page faults
