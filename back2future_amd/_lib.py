@@ -31,6 +31,9 @@ SIGNATURES = {
                                    C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "b2f_compute_flow_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
+    "b2f_compute_flow_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
+                                            C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "b2f_forward_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "b2f_forward": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(c_float_p), C.c_int]),

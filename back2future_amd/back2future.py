@@ -112,9 +112,15 @@ class Model(object):
     def computeFlowBatch(self, im1, im2, im3, out=None):
         """n independent triplets at once: inputs n x 3 x H x W.  The library pipelines sub-batches through
         pinned staging buffers; inputs / `out` = (flow f64 n x 2 x H x W, fwd u8 n x 1 x H x W, bwd) that already
-        live in page-locked memory (e.g. views of torch pin_memory() tensors) are DMA'd in place instead."""
-        im1, im2, im3 = _lib.f32(im1), _lib.f32(im2), _lib.f32(im3)
+        live in page-locked memory (e.g. views of torch pin_memory() tensors) are DMA'd in place instead.
+        uint8 inputs (frames as decoded from 8-bit files, value = byte / 255) are uploaded as bytes."""
+        as_bytes = all(np.asarray(a).dtype == np.uint8 for a in (im1, im2, im3))
+        if as_bytes:
+            im1, im2, im3 = (np.ascontiguousarray(a) for a in (im1, im2, im3))
+        else:
+            im1, im2, im3 = _lib.f32(im1), _lib.f32(im2), _lib.f32(im3)
         n, _, H0, W0 = im1.shape
+        assert im1.shape == im2.shape == im3.shape and im1.shape[1] == 3, "expected three n x 3 x H x W arrays"
         if out is not None:
             flow, fwd, bwd = out
             assert flow.dtype == np.float64 and flow.shape == (n, 2, H0, W0) and flow.flags.c_contiguous
@@ -124,10 +130,13 @@ class Model(object):
             flow = np.empty((n, 2, H0, W0), np.float64)
             fwd = np.empty((n, 1, H0, W0), np.uint8)
             bwd = np.empty((n, 1, H0, W0), np.uint8)
-        _lib.check(_lib.lib().b2f_compute_flow_batch(
-            self._h, n, _lib.fptr(im1), _lib.fptr(im2), _lib.fptr(im3), H0, W0,
-            flow.ctypes.data_as(C.POINTER(C.c_double)), fwd.ctypes.data_as(C.POINTER(C.c_ubyte)),
-            bwd.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        outp = (flow.ctypes.data_as(C.POINTER(C.c_double)), fwd.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                bwd.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if as_bytes:
+            u8p = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+            _lib.check(_lib.lib().b2f_compute_flow_batch_u8(self._h, n, u8p(im1), u8p(im2), u8p(im3), H0, W0, *outp))
+        else:
+            _lib.check(_lib.lib().b2f_compute_flow_batch(self._h, n, _lib.fptr(im1), _lib.fptr(im2), _lib.fptr(im3), H0, W0, *outp))
         return flow, fwd, bwd
 
     def output_shapes(self, H, W):

@@ -1070,8 +1070,9 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
 // (back2future.lua:80-84), exactly the reference's arithmetic.  Host threads (B2F_HOST_THREADS, default 16, two
 // thirds on the input side; the output side is driven by a second control thread) do the packing / staging and
 // the f32 -> f64 conversion; page-locked caller buffers are DMA'd in place where no conversion is involved.
-int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
-                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+namespace {
+int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, const void *im3, bool bytes_in, int H0,
+                          int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
 {
     if (!c || !im1 || !im2 || !im3 || !flow || !fwd_occ || !bwd_occ) return fail("b2f_compute_flow: null argument");
     if (n <= 0 || H0 <= 0 || W0 <= 0) return fail("b2f_compute_flow: bad shape");
@@ -1086,7 +1087,8 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
     const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (16ll << 20);
     const int nthreads = std::max(2, getenv("B2F_HOST_THREADS") ? atoi(getenv("B2F_HOST_THREADS"))
                                                                  : (int)std::min(16u, std::thread::hardware_concurrency()));
-    const bool use_u8 = !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
+    const bool use_u8 = bytes_in || !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
+    const size_t esz = bytes_in ? 1 : 4;   // bytes per input sample in the caller's buffers
     const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
     // sub-batch sizes ramp up 1, 2, 4, ... SB: the kernels start after one triplet's upload instead of SB of them
     // (B2F_HOST_RAMP=0: uniform sizes)
@@ -1101,8 +1103,9 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
 
     if (!c->s_in) HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     if (!c->s_out) HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    const bool stage_in = !(is_pinned(im1, (size_t)n * 3 * hw0 * 4) && is_pinned(im2, (size_t)n * 3 * hw0 * 4) &&
-                            is_pinned(im3, (size_t)n * 3 * hw0 * 4));
+    const bool pinned_in = is_pinned(im1, (size_t)n * 3 * hw0 * esz) && is_pinned(im2, (size_t)n * 3 * hw0 * esz) &&
+                           is_pinned(im3, (size_t)n * 3 * hw0 * esz);
+    const bool stage_in = !pinned_in && !bytes_in;   // float staging buffer (byte inputs stage through h_u8)
     const bool stage_masks = !(is_pinned(fwd_occ, (size_t)n * hw0) && is_pinned(bwd_occ, (size_t)n * hw0));
     for (int k = 0; k < std::min(nsub, 2); ++k)
         CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_masks, use_u8));
@@ -1111,7 +1114,7 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
     if (!c->pool_in || c->pool_in->workers() != w_in) c->pool_in.reset(new CopyPool(w_in));
     if (!c->pool_out || c->pool_out->workers() != w_out) c->pool_out.reset(new CopyPool(w_out));
 
-    const float *ims[3] = {im1, im2, im3};
+    const char *ims[3] = {(const char *)im1, (const char *)im2, (const char *)im3};
     // ---- output side: a second control thread hands finished downloads to the caller ----
     std::mutex mu;
     std::condition_variable cv;
@@ -1168,11 +1171,26 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
         std::vector<int> as_u8(nb, 0);
         for (int t = 0; t < nb; ++t) {
             float *dst = hs.d_up + (size_t)t * 9 * hw0;
+            if (bytes_in) {   // the caller's samples are the bytes: value = k / 255
+                unsigned char *du = hs.d_u8 + (size_t)t * 9 * hw0;
+                if (pinned_in) {
+                    for (int f = 0; f < 3; ++f)
+                        HIPCHK(hipMemcpyAsync(du + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0, hipMemcpyHostToDevice, c->s_in));
+                } else {
+                    unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
+                    std::vector<CopyJob> jobs;
+                    for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0});
+                    c->pool_in->run(jobs);
+                    HIPCHK(hipMemcpyAsync(du, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
+                }
+                as_u8[t] = 1;
+                continue;
+            }
             if (try_u8) {
                 unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
                 std::vector<CopyJob> jobs;
                 for (int f = 0; f < 3; ++f)
-                    jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact});
+                    jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact});
                 c->pool_in->run(jobs);
                 if (!inexact.load()) {
                     HIPCHK(hipMemcpyAsync(hs.d_u8 + (size_t)t * 9 * hw0, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
@@ -1184,12 +1202,12 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
             if (stage_in) {
                 float *st = hs.h_in + (size_t)t * 9 * hw0;
                 std::vector<CopyJob> jobs;
-                for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4});
+                for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4});
                 c->pool_in->run(jobs);
                 HIPCHK(hipMemcpyAsync(dst, st, 9 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
             } else {
                 for (int f = 0; f < 3; ++f)
-                    HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
+                    HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
             }
         }
         HIPCHK(hipEventRecord(hs.ev_in, c->s_in));
@@ -1242,6 +1260,21 @@ int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2
         return fail(msg);
     }
     return 0;
+}
+
+}  // namespace
+
+int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
+                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+{
+    return compute_flow_pipeline(c, n, im1, im2, im3, false, H0, W0, flow, fwd_occ, bwd_occ);
+}
+
+int b2f_compute_flow_batch_u8(b2f_ctx *c, int n, const unsigned char *im1, const unsigned char *im2,
+                              const unsigned char *im3, int H0, int W0, double *flow, unsigned char *fwd_occ,
+                              unsigned char *bwd_occ)
+{
+    return compute_flow_pipeline(c, n, im1, im2, im3, true, H0, W0, flow, fwd_occ, bwd_occ);
 }
 
 int b2f_compute_flow(b2f_ctx *c, const float *im1, const float *im2, const float *im3, int H0, int W0,

@@ -163,6 +163,36 @@ def pmc_traffic(B, H, W):
     return d
 
 
+def host_path(torch, model, H, W, n=32):
+    """PCIe-inclusive rate of the host-buffer boundary (SURVEY 8d "end-to-end incl. H2D/D2H"): computeFlowBatch on n
+    triplets in pageable host memory -> f64 flow + u8 masks in host memory.  Reported beside `value`, never as it."""
+    import numpy as np
+    g = torch.Generator(device="cuda").manual_seed(7)
+    by = [torch.randint(0, 256, (n, 3, H, W), generator=g, device="cuda", dtype=torch.uint8).cpu().numpy() for _ in range(3)]
+    nf = n // 2
+    fl = [torch.rand((nf, 3, H, W), generator=g, device="cuda").cpu().numpy() for _ in range(3)]
+    out = (np.empty((n, 2, H, W), np.float64), np.empty((n, 1, H, W), np.uint8), np.empty((n, 1, H, W), np.uint8))
+
+    def best(fn, reps=2):
+        fn()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        return min(t)
+
+    t_b = best(lambda: model.computeFlowBatch(*by, out=out))
+    o16 = tuple(o[:nf] for o in out)
+    t_f = best(lambda: model.computeFlowBatch(*fl, out=o16))
+    o1 = tuple(o[:1] for o in out)
+    t_1 = best(lambda: model.computeFlowBatch(*[a[:1] for a in by], out=o1), reps=3)
+    return {"what": "b2f_compute_flow_batch[_u8]: host buffers in (pageable), f64 flow + u8 masks out, upload / kernels / "
+                    "download pipelined; not `value` (that starts from HBM-resident inputs)",
+            "unit": "triplets/s", "bytes_in": {"n": n, "value": n / t_b}, "float_in": {"n": nf, "value": nf / t_f},
+            "single_triplet_ms_bytes_in": 1e3 * t_1, "finite": bool(np.isfinite(out[0]).all())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +203,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--graph", type=int, default=0, help="1: replay a captured hipGraph (no per-kernel events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -298,6 +329,8 @@ def main():
                                         "traffic_unit": "HBM bytes per step (PMC)", "traffic_source": tr.get("file"),
                                         "ms_per_step": corr_ms, "algorithmic_bytes_per_step": cb}
             out["kernel_ms_per_step"] = {k: ms / args.steps for k, (ms, n) in sorted(prof.items())}
+        if world == 1 and not args.no_host_path:
+            out["host_path"] = host_path(torch, model, H, W)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, 2)
         print(json.dumps(out), flush=True)

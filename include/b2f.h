@@ -99,6 +99,13 @@ B2F_API int b2f_compute_flow(b2f_ctx *ctx, const float *im1, const float *im2, c
 B2F_API int b2f_compute_flow_batch(b2f_ctx *ctx, int n, const float *im1, const float *im2,
                            const float *im3, int H0, int W0, double *flow,
                            unsigned char *fwd_occ, unsigned char *bwd_occ);
+/* Same for frames that are still 8-bit (n x 3 x H0 x W0 bytes, planar RGB): the value of a
+ * sample is byte / 255, the float image.load() [torch/image] makes of it, so the results are
+ * those of b2f_compute_flow_batch on the converted floats, bit for bit, at a quarter of the
+ * upload ("n x 9 x H x W f32 or ... u8").                                     */
+B2F_API int b2f_compute_flow_batch_u8(b2f_ctx *ctx, int n, const unsigned char *im1,
+                              const unsigned char *im2, const unsigned char *im3, int H0, int W0,
+                              double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
 
 /* ---- the hot path, device boundary: model:forward(imgs) (back2future.lua:74) ----
  * dev_in: B x 9 x H x W planar fp32 on the GPU (the tensor `imgs` of :73), H and W

@@ -282,6 +282,14 @@ def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
     for a, b in zip(ref + ref4, got + got4):
         np.testing.assert_array_equal(a, b)
     assert np.abs(ref[0]).max() > 0
+    # the byte entry point: value = byte / 255, same results as the converted floats
+    by = [np.round(a[:3] * 255.0).astype(np.uint8) for a in im]
+    for a, b in zip(ref4, hard.computeFlowBatch(*by)):
+        np.testing.assert_array_equal(a, b)
+    import torch
+    pin = [torch.from_numpy(a).pin_memory() for a in by]
+    for a, b in zip(ref4, hard.computeFlowBatch(*[t.numpy() for t in pin])):
+        np.testing.assert_array_equal(a, b)
 
 
 def test_batch_equals_single(soft):

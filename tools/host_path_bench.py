@@ -61,6 +61,14 @@ def main():
     t = timed(lambda: m.computeFlowBatch(*pin_np, out=out_np))
     res["pinned_triplets_per_s"] = n / t
     assert np.array_equal(out_np[0], out_pg[0]) and np.array_equal(out_np[1], out_pg[1])
+    if a.u8:   # 2b. the byte entry point (frames still 8-bit): no packing pass on the host
+        by = [torch.round(t_ * 255.0).to(torch.uint8).numpy() for t_ in ims]
+        t = timed(lambda: m.computeFlowBatch(*by, out=out_pg))
+        res["bytes_in_triplets_per_s"] = n / t
+        assert np.array_equal(out_np[0], out_pg[0])
+        one_b = [b_[0:1] for b_ in by]
+        o1b = tuple(o[0:1] for o in out_pg)
+        res["single_triplet_ms_bytes_in"] = timed(lambda: m.computeFlowBatch(*one_b, out=o1b)) * 1e3
     # 3. one triplet at a time (the reference's computeFlow signature): latency
     one = [p[0] for p in pg]
     t = timed(lambda: m.computeFlow(*one))
