@@ -229,6 +229,7 @@ struct b2f_ctx {
     int wsB = 0, wsH = 0, wsW = 0;
     // options
     int use_graph = 0, profile = 0;
+    int host_graph = 1;   // b2f_compute_flow*: replay hipGraphs for repeated (shape, sub-batch) combinations
     std::map<GraphKey, hipGraphExec_t> graphs;
     // profiling
     std::vector<std::string> prof_names;
@@ -481,6 +482,13 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     return p;
 }
 
+void drop_graphs(b2f_ctx *c)
+{
+    for (auto &g : c->graphs)
+        if (g.second) (void)hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+}
+
 int ensure_workspace(b2f_ctx *c, const Plan &p)
 {
     if (p.total > c->arena_floats) {
@@ -488,8 +496,7 @@ int ensure_workspace(b2f_ctx *c, const Plan &p)
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipFree(c->arena));
             c->arena = nullptr;
-            for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
-            c->graphs.clear();
+            drop_graphs(c);
         }
         HIPCHK(hipMalloc(&c->arena, p.total * sizeof(float)));
         HIPCHK(hipMemset(c->arena, 0, p.total * sizeof(float)));
@@ -515,9 +522,24 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
              int stride, int leaky, float *out)
 {
     const PackedConv &p = c->packed[conv_id];
-    // kernel for this call: F(4x4) layers fall back to their F(2x2) packing on small maps
-    static const int small_px = getenv("B2F_WINO4_MIN_PIXELS") ? atoi(getenv("B2F_WINO4_MIN_PIXELS")) : 4096;
-    const bool alt = p.wino == 4 && H * W < small_px;
+    // kernel for this call: F(4x4) layers fall back to their F(2x2) packing when the launch would leave most of
+    // the chip idle.  An F(4x4) block (16 x 32 pixels, one per CU) takes about three times as long as an F(2x2)
+    // block (8 x 16 pixels) that has its CU to itself and 1.5 times as long as one that shares it with a second
+    // block, so compare the number of block rounds each kernel needs on 256 CUs.
+    // (B2F_WINO4_MIN_PIXELS=n: plain rule instead, F(2x2) below n pixels per map.)
+    static const int small_px = getenv("B2F_WINO4_MIN_PIXELS") ? atoi(getenv("B2F_WINO4_MIN_PIXELS")) : -1;
+    bool alt = false;
+    if (p.wino == 4) {
+        if (small_px >= 0) {
+            alt = H * W < small_px;
+        } else {
+            const long b4 = (long)nimg * ((H + 15) / 16) * ((W + 31) / 32) * p.nblk;
+            const long b2 = (long)nimg * ((H + 7) / 8) * ((W + 15) / 16) * p.nblk2;
+            const long t4 = 3 * ((b4 + 255) / 256);
+            const long t2 = b2 <= 256 ? 1 : 2 * ((b2 + 511) / 512);
+            alt = t2 < t4;
+        }
+    }
     const int mode = alt ? 2 : p.wino;
     const int nt = alt ? p.nt2 : p.nt, nblk = alt ? p.nblk2 : p.nblk;
     ConvLaunch L;
@@ -844,7 +866,7 @@ void b2f_destroy(b2f_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    drop_graphs(c);
     for (ProfEvent &pe : c->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (HostSlot &hs : c->slot) {
@@ -915,6 +937,7 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value)
 {
     if (!c || !key) return fail("b2f_set_option: null argument");
     if (!strcmp(key, "use_graph")) c->use_graph = value;
+    else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else return fail(std::string("b2f_set_option: unknown key ") + key);
     return 0;
@@ -951,24 +974,29 @@ int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launc
     return 0;
 }
 
-int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow,
-                       float *dev_occ, float *dev_est3, void *stream)
+namespace {
+// model:forward on device pointers.  With `graph` the ~150 launches of a (shape, pointers) combination are replayed
+// from a hipGraph: the first call of a combination runs eagerly (and lets the kernels set their function
+// attributes, which must not happen inside a capture), the second one captures, later ones only replay.  Worth
+// ~0.5 ms per forward pass: 17 % of a single full-HD triplet, 2 % of a batch of 16.
+int forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow, float *dev_occ,
+                   float *dev_est3, hipStream_t s, bool graph)
 {
-    if (!c || !dev_in) return fail("b2f_forward_device: null argument");
     CHK(check_shape(B, H, W));
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const Plan P = make_plan(B, H, W, false, c->past_flow);
     CHK(ensure_workspace(c, P));
     Outs O;
     O.flow = dev_flow; O.occ = dev_occ; O.est3 = dev_est3;
-    if (c->use_graph && !c->profile) {
+    if (graph && !c->profile) {
+        if (c->graphs.size() > 256) drop_graphs(c);   // callers that keep changing pointers: start over
         const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
-            // one eager pass first: kernels set their function attributes (dynamic LDS size) on
-            // first launch, which must not happen inside a stream capture
-            CHK(forward_impl(c, s, false, dev_in, in_kind, P, O));
+            c->graphs.emplace(key, nullptr);
+            return forward_impl(c, s, false, dev_in, in_kind, P, O);
+        }
+        if (!it->second) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int rc = forward_impl(c, s, true, dev_in, in_kind, P, O);
@@ -976,14 +1004,24 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
             if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
             HIPCHK(e);
             hipGraphExec_t ge = nullptr;
-            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
-            it = c->graphs.emplace(key, ge).first;
+            HIPCHK(ei);
+            it->second = ge;
         }
         HIPCHK(hipGraphLaunch(it->second, s));
         return 0;
     }
     return forward_impl(c, s, false, dev_in, in_kind, P, O);
+}
+}  // namespace
+
+int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow,
+                       float *dev_occ, float *dev_est3, void *stream)
+{
+    if (!c || !dev_in) return fail("b2f_forward_device: null argument");
+    return forward_device(c, dev_in, in_kind, B, H, W, dev_flow, dev_occ, dev_est3, stream ? (hipStream_t)stream : c->stream,
+                          c->use_graph != 0);
 }
 
 // ---- host-buffer entry point: a double-buffered upload / compute / download pipeline ----------------
@@ -1020,8 +1058,7 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
             HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipFree(hs.dev));
             hs.dev = nullptr; hs.dev_bytes = 0;
-            for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);   // graphs are keyed on slot pointers
-            c->graphs.clear();
+            drop_graphs(c);   // graphs are keyed on slot pointers
         }
         HIPCHK(hipMalloc(&hs.dev, need_dev));
         hs.dev_bytes = need_dev;
@@ -1090,11 +1127,12 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
     const bool use_u8 = bytes_in || !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
     const size_t esz = bytes_in ? 1 : 4;   // bytes per input sample in the caller's buffers
     const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
-    // sub-batch sizes ramp up 1, 2, 4, ... SB: the kernels start after one triplet's upload instead of SB of them
-    // (B2F_HOST_RAMP=0: uniform sizes)
+    // sub-batch sizes ramp up from ~2 Mpx (one full-HD triplet) by doubling to SB: the kernels start after a small
+    // upload instead of SB triplets' (B2F_HOST_RAMP=0: uniform sizes)
     const bool ramp = !(getenv("B2F_HOST_RAMP") && atoi(getenv("B2F_HOST_RAMP")) == 0);
+    const int sz0 = ramp ? (int)std::min<long long>(SB, std::max<long long>(1, (2ll << 20) / (long long)hw0)) : SB;
     std::vector<std::pair<size_t, int>> subs;   // (first triplet, count)
-    for (int b0 = 0, sz = ramp ? 1 : SB; b0 < n; sz = std::min(2 * sz, SB)) {
+    for (int b0 = 0, sz = sz0; b0 < n; sz = std::min(2 * sz, SB)) {
         const int nb = std::min(sz, n - b0);
         subs.push_back({(size_t)b0, nb});
         b0 += nb;
@@ -1219,7 +1257,8 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
         // ColorNormalize, then image.scale to the /64 size (:50-71); without a rescale the raw planes go to the
         // network as they are and the first conv kernel normalizes on the fly
         if (!same) HIPCHK(launch_image_scale(hs.d_up, 1, (long)nb * 9, H0, W0, hs.d_tmp, hs.d_in, fh, fw, c->stream));
-        CHK(b2f_forward_device(c, hs.d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, nb, fh, fw, hs.d_flow, nullptr, hs.d_est3, c->stream));
+        CHK(forward_device(c, hs.d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, nb, fh, fw, hs.d_flow, nullptr, hs.d_est3, c->stream,
+                           c->host_graph != 0));
         HIPCHK(launch_postprocess(hs.d_flow, hs.d_est3, C3, nb, fh, fw, H0, W0, same ? nullptr : hs.d_flow32, hs.d_fo, hs.d_bo, c->stream));
         HIPCHK(hipEventRecord(hs.ev_comp, c->stream));
         // ---- download: the set's pinned output buffers must have been handed over (k - 2 drained)

@@ -174,7 +174,8 @@ def host_path(torch, model, H, W, n=32):
     out = (np.empty((n, 2, H, W), np.float64), np.empty((n, 1, H, W), np.uint8), np.empty((n, 1, H, W), np.uint8))
 
     def best(fn, reps=2):
-        fn()
+        fn()                                   # buffers, page faults
+        fn()                                   # hipGraph capture (second use of a shape)
         t = []
         for _ in range(reps):
             t0 = time.perf_counter()

@@ -125,8 +125,10 @@ B2F_API int b2f_forward_device(b2f_ctx *ctx, const void *dev_in, int in_kind, in
 B2F_API int b2f_forward(b2f_ctx *ctx, const float *x, int B, int H, int W, float **outs, int n_outs);
 B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh, int *ow, int cap);
 
-/* Execution options: use_graph = capture the forward into a hipGraph per shape and
- * replay it; profile = record HIP events around every kernel launch (eager mode).   */
+/* Execution options: use_graph (default 0) = b2f_forward_device replays a hipGraph per
+ * (shape, pointers) combination, captured on its second use; host_graph (default 1) = the
+ * same inside b2f_compute_flow*; profile = record HIP events around every kernel launch
+ * (eager mode).                                                                       */
 B2F_API int b2f_set_option(b2f_ctx *ctx, const char *key, int value);
 /* Per-kernel-class timings gathered while profile=1.  names: cap x 32 chars.        */
 B2F_API int b2f_profile_read(b2f_ctx *ctx, char *names, double *total_ms, long long *launches,

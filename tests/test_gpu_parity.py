@@ -292,6 +292,26 @@ def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
         np.testing.assert_array_equal(a, b)
 
 
+def test_host_path_graph_replay_identical(soft):
+    """computeFlow replays a hipGraph from the third call of a shape on (eager, capture, replay): the results must
+    not change by a bit, nor differ from a context with graphs switched off."""
+    r = _rng(5)
+    t = _triplet(r, 150, 200)
+    soft.set_option("host_graph", 0)
+    ref = soft.computeFlow(*t)
+    soft.set_option("host_graph", 1)
+    for _ in range(4):
+        got = soft.computeFlow(*t)
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+    t2 = _triplet(r, 150, 200)                     # other data through the captured graph
+    got2 = soft.computeFlow(*t2)
+    soft.set_option("host_graph", 0)
+    for a, b in zip(soft.computeFlow(*t2), got2):
+        np.testing.assert_array_equal(a, b)
+    soft.set_option("host_graph", 1)
+
+
 def test_batch_equals_single(soft):
     r = _rng(9)
     trip = [_triplet(r, 64, 128) for _ in range(3)]
@@ -310,7 +330,7 @@ def test_graph_replay_matches_eager(soft):
     B, H, Wd = 2, 64, 128
     x = torch.from_numpy(r.standard_normal((B, 9, H, Wd)).astype(np.float32)).cuda()
     outs = []
-    for use_graph in (0, 1, 1):
+    for use_graph in (0, 1, 1, 1):        # eager; first sight (eager); capture + replay; replay
         soft.set_option("use_graph", use_graph)
         flow = torch.zeros(B, 2, H, Wd, device="cuda"); occ = torch.zeros(B, 2, H, Wd, device="cuda")
         soft.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), occ.data_ptr())

@@ -38,7 +38,8 @@ def main():
     res = {"n": n, "H": H, "W": W, "u8_data": a.u8, "env": {k: v for k, v in os.environ.items() if k.startswith("B2F_")}}
 
     def timed(fn):
-        fn()                                   # buffers, graphs, page faults
+        fn()                                   # buffers, page faults
+        fn()                                   # hipGraph capture (second use of a shape)
         best = 1e30
         for _ in range(a.reps):
             t = time.perf_counter()
