@@ -1,247 +1,24 @@
-// C-ABI layer of libb2f.so (include/b2f.h): context, weight packing, workspace, the
-// computeFlow pipeline (back2future.lua:47-95 around models/pwc.lua's graph), hipGraph
+// C-ABI layer of libb2f.so (include/b2f.h): context, weight packing, workspace, the forward
+// pass of models/pwc.lua's graph (the host-buffer boundary around it: b2f_pipeline.hip), hipGraph
 // capture, per-kernel HIP-event profiling, and op-level entry points for parity tests.
-#include "../../include/b2f.h"
+#include "b2f_ctx.h"
 
-#include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
-#include <condition_variable>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <tuple>
-#include <vector>
-
-#include "b2f_host.h"
-#include "b2f_internal.h"
 
 using namespace b2f;
 
 static thread_local std::string g_err;
-static int fail(const std::string &m)
+namespace b2f {
+int api_fail(const std::string &m)
 {
     g_err = m;
     return 1;
 }
-#define HIPCHK(expr)                                                                         \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-    } while (0)
-#define CHK(expr)                         \
-    do {                                  \
-        int rc_ = (expr);                 \
-        if (rc_ != 0) return rc_;         \
-    } while (0)
-
-namespace {
-
-struct PackedConv {
-    int nseg = 1;
-    int chunks[2] = {0, 0};
-    int cout = 0, nt = 1, nblk = 1;
-    int wino = 0;                  // 0 direct kernel, 1 VALU kernel for 2 outputs, 2 Winograd F(2x2,3x3), 3 16->16 kernel,
-                                   // 4 Winograd F(4x4,3x3)
-    size_t w_off = 0, b_off = 0;   // float offsets into wpk_dev
-    // F(4x4) layers also carry an F(2x2) packing for small maps (one 16 x 32-pixel block per CU does not fill
-    // the chip below ~64 x 64 pixels; measured at 32 x 60: 0.05 ms vs 0.14 ms)
-    int nt2 = 0, nblk2 = 0;
-    size_t w_off2 = 0, b_off2 = 0;
-};
-
-struct ProfEvent {
-    int name;
-    hipEvent_t a, b;
-};
-
-struct GraphKey {
-    const void *in;
-    float *flow, *occ, *est3;
-    int kind, B, H, W;
-    bool operator<(const GraphKey &o) const
-    {
-        return std::tie(in, flow, occ, est3, kind, B, H, W) < std::tie(o.in, o.flow, o.occ, o.est3, o.kind, o.B, o.H, o.W);
-    }
-};
-
-// One of the two buffer sets the host-buffer entry point (b2f_compute_flow_batch) alternates between: while the
-// kernels of sub-batch k run on set k & 1, the uploads of k + 1 and the downloads of k - 1 use the other one.
-struct HostSlot {
-    char *dev = nullptr;        // device blob, carved below
-    size_t dev_bytes = 0;
-    char *pin = nullptr;        // pinned staging blob
-    size_t pin_bytes = 0;
-    unsigned char *d_u8 = nullptr;   // 8-bit transport of the input planes (see pack_u8_piece)
-    float *d_up = nullptr, *d_tmp = nullptr, *d_in = nullptr, *d_flow = nullptr, *d_est3 = nullptr;
-    float *d_flow32 = nullptr;       // flow at H0 x W0 (fp32, before the f64 sc_w / sc_h factors); = d_flow without a rescale
-    unsigned char *d_fo = nullptr, *d_bo = nullptr;
-    unsigned char *h_u8 = nullptr;
-    float *h_in = nullptr, *h_flow32 = nullptr;
-    unsigned char *h_fo = nullptr, *h_bo = nullptr;
-    hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
-};
-
-// Host work items of the pipeline, cut into pieces and spread over a pool of threads.
-enum { JOB_COPY = 0, JOB_F32_TO_F64 = 1, JOB_PACK_U8 = 2 };
-struct CopyJob {
-    void *dst;
-    const void *src;
-    size_t bytes;                     // of the source
-    int kind = JOB_COPY;
-    double scale = 1.0;               // JOB_F32_TO_F64: dst = (double)src * scale   (back2future.lua:83-84)
-    std::atomic<int> *inexact = nullptr;   // JOB_PACK_U8: set when a value is not k / 255
-};
-
-// 8-bit transport: image.load hands computeFlow floats that came from 8-bit files, i.e. k / 255.  Such a plane
-// crosses the link as bytes (a quarter of the traffic of a path that is PCIe-bound) and is rebuilt on the device
-// by the same correctly rounded division, but only if that reproduces every float of it bit for bit; one other
-// value (or -0, NaN, ...) and the triplet is uploaded as floats instead.
-inline bool pack_u8_piece(unsigned char *d, const float *s, size_t n)
-{
-    uint32_t bad = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const float v = s[i];
-        int k = (int)(v * 255.0f + 0.5f);
-        k = k < 0 ? 0 : (k > 255 ? 255 : k);
-        const float r = (float)k / 255.0f;
-        uint32_t vb, rb;
-        memcpy(&vb, &v, 4);
-        memcpy(&rb, &r, 4);
-        bad |= vb ^ rb;
-        d[i] = (unsigned char)k;
-    }
-    return bad == 0;
-}
-
-inline void run_piece(const CopyJob &j)
-{
-    if (j.kind == JOB_COPY) {
-        memcpy(j.dst, j.src, j.bytes);
-    } else if (j.kind == JOB_F32_TO_F64) {
-        const float *s = (const float *)j.src;
-        double *d = (double *)j.dst;
-        const double sc = j.scale;
-        for (size_t i = 0, n = j.bytes / 4; i < n; ++i) d[i] = (double)s[i] * sc;
-    } else {
-        if (!pack_u8_piece((unsigned char *)j.dst, (const float *)j.src, j.bytes / 4)) j.inexact->store(1, std::memory_order_relaxed);
-    }
-}
-
-// Persistent host threads that execute job lists in 1 MB pieces (the caller's thread works too).  One core moves
-// ~10 GB/s; a full-HD triplet is 71 MB in and 35 MB out, so single-threaded staging would cost several times the
-// 1.5 ms the GPU needs for it.
-class CopyPool {
-public:
-    explicit CopyPool(int workers)
-    {
-        for (int i = 0; i < workers; ++i) th_.emplace_back([this] { worker(); });
-    }
-    ~CopyPool()
-    {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (std::thread &t : th_) t.join();
-    }
-    int workers() const { return (int)th_.size(); }
-    void run(const std::vector<CopyJob> &jobs)
-    {
-        constexpr size_t kPiece = 1 << 20;
-        std::vector<CopyJob> pieces;
-        size_t bytes = 0;
-        for (const CopyJob &j : jobs) {
-            const size_t dmul = j.kind == JOB_F32_TO_F64 ? 2 : 1, ddiv = j.kind == JOB_PACK_U8 ? 4 : 1;
-            for (size_t o = 0; o < j.bytes; o += kPiece) {
-                CopyJob q = j;
-                q.dst = (char *)j.dst + o * dmul / ddiv;
-                q.src = (const char *)j.src + o;
-                q.bytes = std::min(kPiece, j.bytes - o);
-                pieces.push_back(q);
-            }
-            bytes += j.bytes;
-        }
-        if (th_.empty() || bytes < (2u << 20)) {
-            for (const CopyJob &j : pieces) run_piece(j);
-            return;
-        }
-        std::unique_lock<std::mutex> l(m_);
-        pieces_ = &pieces;
-        next_ = done_ = 0;
-        cv_.notify_all();
-        while (next_ < pieces.size()) {
-            const CopyJob j = pieces[next_++];
-            l.unlock();
-            run_piece(j);
-            l.lock();
-            ++done_;
-        }
-        cv_done_.wait(l, [&] { return done_ == pieces.size(); });
-        pieces_ = nullptr;
-    }
-
-private:
-    void worker()
-    {
-        std::unique_lock<std::mutex> l(m_);
-        for (;;) {
-            cv_.wait(l, [&] { return stop_ || (pieces_ && next_ < pieces_->size()); });
-            if (stop_) return;
-            const CopyJob j = (*pieces_)[next_++];
-            l.unlock();
-            run_piece(j);
-            l.lock();
-            if (++done_ == pieces_->size()) cv_done_.notify_all();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, cv_done_;
-    const std::vector<CopyJob> *pieces_ = nullptr;
-    size_t next_ = 0, done_ = 0;
-    bool stop_ = false;
-};
-
-}  // namespace
-
-struct b2f_ctx {
-    int device = 0;
-    bool past_flow = false;
-    long long nparams = 0;
-    hipStream_t stream = nullptr;
-    std::vector<ConvDesc> lay;
-    std::vector<PackedConv> packed;
-    float *w_dev = nullptr;     // flat canonical weights
-    float *wpk_dev = nullptr;   // packed kernel-side copies
-    size_t wpk_floats = 0;
-    size_t first_w_off = 0, first_b_off = 0;   // [27][16] weights + bias of the first pyramid conv (conv_first_kernel)
-    // workspace arena
-    float *arena = nullptr;
-    size_t arena_floats = 0;
-    int wsB = 0, wsH = 0, wsW = 0;
-    // options
-    int use_graph = 0, profile = 0;
-    int host_graph = 1;   // b2f_compute_flow*: replay hipGraphs for repeated (shape, sub-batch) combinations
-    std::map<GraphKey, hipGraphExec_t> graphs;
-    // profiling
-    std::vector<std::string> prof_names;
-    std::vector<double> prof_ms;
-    std::vector<long long> prof_n;
-    std::vector<ProfEvent> prof_pending;
-    std::vector<hipEvent_t> ev_pool;
-    // host-buffer pipeline (b2f_compute_flow_batch)
-    hipStream_t s_in = nullptr, s_out = nullptr;
-    HostSlot slot[2];
-    std::unique_ptr<CopyPool> pool_in, pool_out;
-};
+const std::string &api_error() { return g_err; }
+}  // namespace b2f
+static int fail(const std::string &m) { return api_fail(m); }
 
 namespace {
 
@@ -482,12 +259,14 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     return p;
 }
 
-void drop_graphs(b2f_ctx *c)
+}  // namespace
+void b2f::drop_graphs(b2f_ctx *c)
 {
     for (auto &g : c->graphs)
         if (g.second) (void)hipGraphExecDestroy(g.second);
     c->graphs.clear();
 }
+namespace {
 
 int ensure_workspace(b2f_ctx *c, const Plan &p)
 {
@@ -724,12 +503,14 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
     return 0;
 }
 
-int check_shape(int B, int H, int W)
+}  // namespace
+int b2f::check_shape(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return fail("b2f: non-positive shape");
     if (H % 64 || W % 64) return fail("b2f: H and W must be multiples of 64 (7 pyramid levels, back2future.lua:54-67)");
     return 0;
 }
+namespace {
 
 bool parse_random(const char *name, bool *past, unsigned long long *seed, float *gain)
 {
@@ -974,13 +755,14 @@ int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launc
     return 0;
 }
 
-namespace {
+}  // extern "C"
+
 // model:forward on device pointers.  With `graph` the ~150 launches of a (shape, pointers) combination are replayed
 // from a hipGraph: the first call of a combination runs eagerly (and lets the kernels set their function
 // attributes, which must not happen inside a capture), the second one captures, later ones only replay.  Worth
 // ~0.5 ms per forward pass: 17 % of a single full-HD triplet, 2 % of a batch of 16.
-int forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow, float *dev_occ,
-                   float *dev_est3, hipStream_t s, bool graph)
+int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow, float *dev_occ,
+                        float *dev_est3, hipStream_t s, bool graph)
 {
     CHK(check_shape(B, H, W));
     HIPCHK(hipSetDevice(c->device));
@@ -1014,7 +796,8 @@ int forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, in
     }
     return forward_impl(c, s, false, dev_in, in_kind, P, O);
 }
-}  // namespace
+
+extern "C" {
 
 int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow,
                        float *dev_occ, float *dev_est3, void *stream)
@@ -1022,304 +805,6 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
     if (!c || !dev_in) return fail("b2f_forward_device: null argument");
     return forward_device(c, dev_in, in_kind, B, H, W, dev_flow, dev_occ, dev_est3, stream ? (hipStream_t)stream : c->stream,
                           c->use_graph != 0);
-}
-
-// ---- host-buffer entry point: a double-buffered upload / compute / download pipeline ----------------
-namespace {
-
-// true when [p, p + bytes) is page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister,
-// e.g. a torch pin_memory() tensor): such buffers are DMA'd directly, pageable ones go through the pinned slot
-bool is_pinned(const void *p, size_t bytes)
-{
-    for (const char *q : {(const char *)p, (const char *)p + bytes - 1}) {
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (a.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
-
-inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-// carve the slot's device and pinned blobs for sub-batches of up to SB triplets; grows (never shrinks) the blobs
-int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0, int fw, bool same, int C3, bool stage_in,
-                bool stage_masks, bool use_u8)
-{
-    const size_t n_up = align256((size_t)SB * 9 * hw0 * 4), n_u8 = use_u8 ? align256((size_t)SB * 9 * hw0) : 0,
-                 n_in = same ? 0 : align256((size_t)SB * 9 * hw * 4), n_tmp = same ? 0 : align256((size_t)SB * 9 * H0 * fw * 4),
-                 n_flow = align256((size_t)SB * 2 * hw * 4), n_est3 = align256((size_t)SB * C3 * hw * 4),
-                 n_f32 = align256((size_t)SB * 2 * hw0 * 4), n_occ = align256((size_t)SB * hw0);
-    const size_t need_dev = n_up + n_u8 + n_in + n_tmp + n_flow + n_est3 + (same ? 0 : n_f32) + 2 * n_occ;
-    if (need_dev > hs.dev_bytes) {
-        if (hs.dev) {
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipFree(hs.dev));
-            hs.dev = nullptr; hs.dev_bytes = 0;
-            drop_graphs(c);   // graphs are keyed on slot pointers
-        }
-        HIPCHK(hipMalloc(&hs.dev, need_dev));
-        hs.dev_bytes = need_dev;
-    }
-    char *d = hs.dev;
-    hs.d_up = (float *)d; d += n_up;
-    hs.d_u8 = (unsigned char *)d; d += n_u8;
-    hs.d_in = same ? hs.d_up : (float *)d; d += n_in;
-    hs.d_tmp = (float *)d; d += n_tmp;
-    hs.d_flow = (float *)d; d += n_flow;
-    hs.d_est3 = (float *)d; d += n_est3;
-    hs.d_flow32 = same ? hs.d_flow : (float *)d; d += same ? 0 : n_f32;
-    hs.d_fo = (unsigned char *)d; d += n_occ;
-    hs.d_bo = (unsigned char *)d;
-    const size_t need_pin = (stage_in ? n_up : 0) + n_u8 + n_f32 + (stage_masks ? 2 * n_occ : 0);
-    if (need_pin > hs.pin_bytes) {
-        if (hs.pin) {
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipHostFree(hs.pin));
-            hs.pin = nullptr; hs.pin_bytes = 0;
-        }
-        HIPCHK(hipHostMalloc(&hs.pin, need_pin, hipHostMallocDefault));
-        hs.pin_bytes = need_pin;
-    }
-    char *h = hs.pin;
-    hs.h_in = (float *)h; h += stage_in ? n_up : 0;
-    hs.h_u8 = (unsigned char *)h; h += n_u8;
-    hs.h_flow32 = (float *)h; h += n_f32;
-    hs.h_fo = (unsigned char *)h; h += stage_masks ? n_occ : 0;
-    hs.h_bo = (unsigned char *)h;
-    for (hipEvent_t *e : {&hs.ev_in, &hs.ev_comp, &hs.ev_out})
-        if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    return 0;
-}
-
-}  // namespace
-
-// The n triplets are cut into sub-batches (up to B2F_HOST_SUBBATCH_PIXELS input pixels each, default 16 Mpx = eight
-// full-HD triplets) that flow through two buffer sets on three streams: uploads on s_in, ColorNormalize /
-// image.scale / the network / the nearest rescale + thresholds on the context's stream, downloads on s_out.
-// A buffer set's input half is reused as soon as the kernels that read it are done and its output half as soon
-// as its download has been handed over, so in steady state all three streams are busy.
-// The link is the bound of this entry point (one MI355X box: 56 GB/s in either direction, but only 55 GB/s for
-// both together), so both directions carry as few bytes as exactness allows: inputs that are k / 255 go up as
-// bytes (pack_u8_piece), the flow comes down as the network's fp32 values and becomes `double * sc` on the host
-// (back2future.lua:80-84), exactly the reference's arithmetic.  Host threads (B2F_HOST_THREADS, default 16, two
-// thirds on the input side; the output side is driven by a second control thread) do the packing / staging and
-// the f32 -> f64 conversion; page-locked caller buffers are DMA'd in place where no conversion is involved.
-namespace {
-int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, const void *im3, bool bytes_in, int H0,
-                          int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
-{
-    if (!c || !im1 || !im2 || !im3 || !flow || !fwd_occ || !bwd_occ) return fail("b2f_compute_flow: null argument");
-    if (n <= 0 || H0 <= 0 || W0 <= 0) return fail("b2f_compute_flow: bad shape");
-    const int fw = W0 - W0 % 64, fh = H0 - H0 % 64;   // back2future.lua:54-67
-    if (fw <= 0 || fh <= 0) return fail("b2f_compute_flow: image smaller than 64 pixels");
-    CHK(check_shape(1, fh, fw));
-    HIPCHK(hipSetDevice(c->device));
-    const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
-    const bool same = (fw == W0 && fh == H0);
-    const int C3 = c->past_flow ? 2 : 3;
-    const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;   // :78-79
-    const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (16ll << 20);
-    const int nthreads = std::max(2, getenv("B2F_HOST_THREADS") ? atoi(getenv("B2F_HOST_THREADS"))
-                                                                 : (int)std::min(16u, std::thread::hardware_concurrency()));
-    const bool use_u8 = bytes_in || !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
-    const size_t esz = bytes_in ? 1 : 4;   // bytes per input sample in the caller's buffers
-    const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
-    // sub-batch sizes ramp up from ~2 Mpx (one full-HD triplet) by doubling to SB: the kernels start after a small
-    // upload instead of SB triplets' (B2F_HOST_RAMP=0: uniform sizes)
-    const bool ramp = !(getenv("B2F_HOST_RAMP") && atoi(getenv("B2F_HOST_RAMP")) == 0);
-    const int sz0 = ramp ? (int)std::min<long long>(SB, std::max<long long>(1, (2ll << 20) / (long long)hw0)) : SB;
-    std::vector<std::pair<size_t, int>> subs;   // (first triplet, count)
-    for (int b0 = 0, sz = sz0; b0 < n; sz = std::min(2 * sz, SB)) {
-        const int nb = std::min(sz, n - b0);
-        subs.push_back({(size_t)b0, nb});
-        b0 += nb;
-    }
-    const int nsub = (int)subs.size();
-
-    if (!c->s_in) HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-    if (!c->s_out) HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    const bool pinned_in = is_pinned(im1, (size_t)n * 3 * hw0 * esz) && is_pinned(im2, (size_t)n * 3 * hw0 * esz) &&
-                           is_pinned(im3, (size_t)n * 3 * hw0 * esz);
-    const bool stage_in = !pinned_in && !bytes_in;   // float staging buffer (byte inputs stage through h_u8)
-    const bool stage_masks = !(is_pinned(fwd_occ, (size_t)n * hw0) && is_pinned(bwd_occ, (size_t)n * hw0));
-    for (int k = 0; k < std::min(nsub, 2); ++k)
-        CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_masks, use_u8));
-    // the calling thread and the drain thread each count as one worker of their pool
-    const int w_out = std::max(0, nthreads / 3 - 1), w_in = std::max(0, nthreads - nthreads / 3 - 1);
-    if (!c->pool_in || c->pool_in->workers() != w_in) c->pool_in.reset(new CopyPool(w_in));
-    if (!c->pool_out || c->pool_out->workers() != w_out) c->pool_out.reset(new CopyPool(w_out));
-
-    const char *ims[3] = {(const char *)im1, (const char *)im2, (const char *)im3};
-    // ---- output side: a second control thread hands finished downloads to the caller ----
-    std::mutex mu;
-    std::condition_variable cv;
-    int submitted = 0, drained = 0;   // sub-batches whose downloads are enqueued / handed over (guarded by mu)
-    bool abort = false;
-    std::string drain_err;
-    auto drain_loop = [&]() {
-        (void)hipSetDevice(c->device);
-        for (int k = 0; k < nsub; ++k) {
-            {
-                std::unique_lock<std::mutex> l(mu);
-                cv.wait(l, [&] { return submitted > k || abort; });
-                if (abort) return;
-            }
-            HostSlot &hs = c->slot[k & 1];
-            const hipError_t e = hipEventSynchronize(hs.ev_out);
-            if (e == hipSuccess) {
-                const size_t b0 = subs[k].first, nb = (size_t)subs[k].second;
-                std::vector<CopyJob> jobs;
-                // flow_est[1] * sc_w, flow_est[2] * sc_h on the :double() copy of est[1] (:80-84)
-                for (size_t t = 0; t < nb; ++t)
-                    for (int ch = 0; ch < 2; ++ch)
-                        jobs.push_back({flow + ((b0 + t) * 2 + ch) * hw0, hs.h_flow32 + (t * 2 + ch) * hw0, hw0 * 4, JOB_F32_TO_F64,
-                                        ch == 0 ? sc_w : sc_h, nullptr});
-                if (stage_masks) {
-                    jobs.push_back({fwd_occ + b0 * hw0, hs.h_fo, nb * hw0});
-                    jobs.push_back({bwd_occ + b0 * hw0, hs.h_bo, nb * hw0});
-                }
-                c->pool_out->run(jobs);
-            }
-            std::lock_guard<std::mutex> l(mu);
-            if (e != hipSuccess) {
-                drain_err = std::string("download failed: ") + hipGetErrorString(e);
-                abort = true;
-            }
-            drained = k + 1;
-            cv.notify_all();
-            if (abort) return;
-        }
-    };
-    std::thread drainer(drain_loop);
-
-    bool try_u8 = use_u8;             // off for the rest of the call after the first triplet that is not 8-bit data
-    std::atomic<int> inexact{0};
-    auto submit = [&](int k) -> int {
-        HostSlot &hs = c->slot[k & 1];
-        const size_t b0 = subs[k].first;
-        const int nb = subs[k].second;
-        // ---- upload: torch.cat({im1, im2, im3}, 1) (back2future.lua:48) = [triplet][frame][3][H0][W0] on the device.
-        // The set's staging buffers are free once upload k - 2 has left them, its device buffers once the kernels
-        // of k - 2 are done (both events still hold the records of k - 2 here).
-        if (k >= 2) HIPCHK(hipEventSynchronize(hs.ev_in));
-        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->s_in, hs.ev_comp, 0));
-        std::vector<int> as_u8(nb, 0);
-        for (int t = 0; t < nb; ++t) {
-            float *dst = hs.d_up + (size_t)t * 9 * hw0;
-            if (bytes_in) {   // the caller's samples are the bytes: value = k / 255
-                unsigned char *du = hs.d_u8 + (size_t)t * 9 * hw0;
-                if (pinned_in) {
-                    for (int f = 0; f < 3; ++f)
-                        HIPCHK(hipMemcpyAsync(du + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0, hipMemcpyHostToDevice, c->s_in));
-                } else {
-                    unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
-                    std::vector<CopyJob> jobs;
-                    for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0});
-                    c->pool_in->run(jobs);
-                    HIPCHK(hipMemcpyAsync(du, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
-                }
-                as_u8[t] = 1;
-                continue;
-            }
-            if (try_u8) {
-                unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
-                std::vector<CopyJob> jobs;
-                for (int f = 0; f < 3; ++f)
-                    jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact});
-                c->pool_in->run(jobs);
-                if (!inexact.load()) {
-                    HIPCHK(hipMemcpyAsync(hs.d_u8 + (size_t)t * 9 * hw0, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
-                    as_u8[t] = 1;
-                    continue;
-                }
-                try_u8 = false;
-            }
-            if (stage_in) {
-                float *st = hs.h_in + (size_t)t * 9 * hw0;
-                std::vector<CopyJob> jobs;
-                for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4});
-                c->pool_in->run(jobs);
-                HIPCHK(hipMemcpyAsync(dst, st, 9 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
-            } else {
-                for (int f = 0; f < 3; ++f)
-                    HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
-            }
-        }
-        HIPCHK(hipEventRecord(hs.ev_in, c->s_in));
-        // ---- kernels: after the upload, and after download k - 2 has read this set's output buffers
-        HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_in, 0));
-        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_out, 0));
-        for (int t = 0; t < nb; ++t)
-            if (as_u8[t]) HIPCHK(launch_unpack_u8(hs.d_u8 + (size_t)t * 9 * hw0, 9 * hw0, hs.d_up + (size_t)t * 9 * hw0, c->stream));
-        // ColorNormalize, then image.scale to the /64 size (:50-71); without a rescale the raw planes go to the
-        // network as they are and the first conv kernel normalizes on the fly
-        if (!same) HIPCHK(launch_image_scale(hs.d_up, 1, (long)nb * 9, H0, W0, hs.d_tmp, hs.d_in, fh, fw, c->stream));
-        CHK(forward_device(c, hs.d_in, same ? B2F_IN_UNIT : B2F_IN_NORMALIZED, nb, fh, fw, hs.d_flow, nullptr, hs.d_est3, c->stream,
-                           c->host_graph != 0));
-        HIPCHK(launch_postprocess(hs.d_flow, hs.d_est3, C3, nb, fh, fw, H0, W0, same ? nullptr : hs.d_flow32, hs.d_fo, hs.d_bo, c->stream));
-        HIPCHK(hipEventRecord(hs.ev_comp, c->stream));
-        // ---- download: the set's pinned output buffers must have been handed over (k - 2 drained)
-        if (k >= 2) {
-            std::unique_lock<std::mutex> l(mu);
-            cv.wait(l, [&] { return drained >= k - 1 || abort; });
-            if (abort) return fail(drain_err);
-        }
-        HIPCHK(hipStreamWaitEvent(c->s_out, hs.ev_comp, 0));
-        HIPCHK(hipMemcpyAsync(hs.h_flow32, hs.d_flow32, (size_t)nb * 2 * hw0 * 4, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(stage_masks ? hs.h_fo : fwd_occ + b0 * hw0, hs.d_fo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(stage_masks ? hs.h_bo : bwd_occ + b0 * hw0, hs.d_bo, (size_t)nb * hw0, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipEventRecord(hs.ev_out, c->s_out));
-        {
-            std::lock_guard<std::mutex> l(mu);
-            submitted = k + 1;
-        }
-        cv.notify_all();
-        return 0;
-    };
-    int rc = 0;
-    for (int k = 0; k < nsub && !rc; ++k) rc = submit(k);
-    std::string msg = rc ? g_err : std::string();
-    if (rc) {
-        std::lock_guard<std::mutex> l(mu);
-        abort = true;
-    }
-    cv.notify_all();
-    drainer.join();
-    if (!rc && abort) { rc = 1; msg = drain_err; }
-    // nothing of this call may still be in flight when the caller gets its buffers back
-    for (hipStream_t st : {c->s_in, c->stream, c->s_out}) {
-        const hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess && !rc) { rc = 1; msg = std::string("b2f_compute_flow: ") + hipGetErrorString(e); }
-    }
-    if (rc) {
-        (void)hipGetLastError();
-        return fail(msg);
-    }
-    return 0;
-}
-
-}  // namespace
-
-int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
-                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
-{
-    return compute_flow_pipeline(c, n, im1, im2, im3, false, H0, W0, flow, fwd_occ, bwd_occ);
-}
-
-int b2f_compute_flow_batch_u8(b2f_ctx *c, int n, const unsigned char *im1, const unsigned char *im2,
-                              const unsigned char *im3, int H0, int W0, double *flow, unsigned char *fwd_occ,
-                              unsigned char *bwd_occ)
-{
-    return compute_flow_pipeline(c, n, im1, im2, im3, true, H0, W0, flow, fwd_occ, bwd_occ);
-}
-
-int b2f_compute_flow(b2f_ctx *c, const float *im1, const float *im2, const float *im3, int H0, int W0,
-                     double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
-{
-    return b2f_compute_flow_batch(c, 1, im1, im2, im3, H0, W0, flow, fwd_occ, bwd_occ);
 }
 
 int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow, int cap)

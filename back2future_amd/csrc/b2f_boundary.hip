@@ -1,7 +1,7 @@
 // Device side of the computeFlow boundary (/root/reference/back2future.lua:48-93): what the reference does on the
 // host around model:forward -- ColorNormalize, image.scale(..., W, H) 'bilinear' down to multiples of 64, and
 // after the forward pass image.scale(..., 'simple') back to the input size and the 0.6666 thresholds -- runs here
-// on the uploaded planes, so the host only moves bytes (and widens the flow to f64, b2f_api.hip).  The arithmetic
+// on the uploaded planes, so the host only moves bytes (and widens the flow to f64, b2f_pipeline.hip).  The arithmetic
 // is the CPU routines' (oracle/b2f_oracle.c) operation for operation: every output element is produced by one
 // thread with the same sequence of IEEE fp32 operations (the file is built with -ffp-contract=off and correctly
 // rounded division), so the results are bit-identical to the CPU ones.
@@ -115,7 +115,7 @@ hipError_t launch_postprocess(const float *flow_net, const float *est3, int est3
     return hipGetLastError();
 }
 
-// 8-bit transport of input planes whose values are all k / 255 (b2f_api.hip:pack_u8_piece): the same correctly
+// 8-bit transport of input planes whose values are all k / 255 (b2f_ctx.h:pack_u8_piece): the same correctly
 // rounded division rebuilds the caller's floats bit for bit.  n multiple of 4 not required.
 __global__ void unpack_u8_kernel(const unsigned char *in, size_t n, float *out)
 {
