@@ -563,14 +563,15 @@ int b2f_version(void) { return 1000; }
 
 long long b2f_param_count(int past_flow) { return param_count(past_flow != 0); }
 
-int b2f_random_weights(unsigned long long seed, int past_flow, float gain, float *out, long long n)
+int b2f_random_weights(unsigned long long seed, int past_flow, float gain, float *out, long long n) try
 {
     if (!out || n != param_count(past_flow != 0)) return fail("b2f_random_weights: bad buffer size");
     random_weights(seed, past_flow != 0, gain, out);
     return 0;
 }
+B2F_CATCH("b2f_random_weights")
 
-int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *past_flow)
+int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *past_flow) try
 {
     std::vector<float> flat;
     bool past = false;
@@ -585,8 +586,9 @@ int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *
     }
     return 0;
 }
+B2F_CATCH("b2f_load_t7")
 
-int b2f_init(const char *name_or_path, int device, b2f_ctx **out)
+int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
 {
     if (!out) return fail("b2f_init: null out");
     *out = nullptr;
@@ -641,6 +643,7 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out)
     *out = c;
     return 0;
 }
+B2F_CATCH("b2f_init")
 
 void b2f_destroy(b2f_ctx *c)
 {
@@ -665,7 +668,7 @@ void b2f_destroy(b2f_ctx *c)
     delete c;
 }
 
-int b2f_info(const b2f_ctx *c, int *levels, int *win, int *past_flow, int *n_outputs, long long *n_params)
+int b2f_info(const b2f_ctx *c, int *levels, int *win, int *past_flow, int *n_outputs, long long *n_params) try
 {
     if (!c) return fail("b2f_info: null context");
     if (levels) *levels = kLevels;
@@ -675,8 +678,9 @@ int b2f_info(const b2f_ctx *c, int *levels, int *win, int *past_flow, int *n_out
     if (n_params) *n_params = c->nparams;
     return 0;
 }
+B2F_CATCH("b2f_info")
 
-int b2f_set_weights(b2f_ctx *c, const float *host_flat, long long n)
+int b2f_set_weights(b2f_ctx *c, const float *host_flat, long long n) try
 {
     if (!c || !host_flat) return fail("b2f_set_weights: null argument");
     HIPCHK(hipSetDevice(c->device));
@@ -687,24 +691,27 @@ int b2f_set_weights(b2f_ctx *c, const float *host_flat, long long n)
     else return fail("b2f_set_weights: n is neither the Hard nor the Soft parameter count");
     return install_weights(c, host_flat, n, past);
 }
+B2F_CATCH("b2f_set_weights")
 
-int b2f_get_weights(b2f_ctx *c, float *host_flat, long long n)
+int b2f_get_weights(b2f_ctx *c, float *host_flat, long long n) try
 {
     if (!c || !host_flat || n != c->nparams) return fail("b2f_get_weights: bad arguments");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(host_flat, c->w_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_get_weights")
 
-int b2f_weights_device(b2f_ctx *c, void **dev_ptr, long long *n)
+int b2f_weights_device(b2f_ctx *c, void **dev_ptr, long long *n) try
 {
     if (!c || !dev_ptr) return fail("b2f_weights_device: null argument");
     *dev_ptr = c->w_dev;
     if (n) *n = c->nparams;
     return 0;
 }
+B2F_CATCH("b2f_weights_device")
 
-int b2f_commit_weights(b2f_ctx *c)
+int b2f_commit_weights(b2f_ctx *c) try
 {
     if (!c) return fail("b2f_commit_weights: null context");
     HIPCHK(hipSetDevice(c->device));
@@ -713,8 +720,9 @@ int b2f_commit_weights(b2f_ctx *c)
     HIPCHK(hipMemcpy(flat.data(), c->w_dev, flat.size() * sizeof(float), hipMemcpyDeviceToHost));
     return pack_all(c, flat.data());
 }
+B2F_CATCH("b2f_commit_weights")
 
-int b2f_set_option(b2f_ctx *c, const char *key, int value)
+int b2f_set_option(b2f_ctx *c, const char *key, int value) try
 {
     if (!c || !key) return fail("b2f_set_option: null argument");
     if (!strcmp(key, "use_graph")) c->use_graph = value;
@@ -723,16 +731,18 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value)
     else return fail(std::string("b2f_set_option: unknown key ") + key);
     return 0;
 }
+B2F_CATCH("b2f_set_option")
 
-int b2f_synchronize(b2f_ctx *c)
+int b2f_synchronize(b2f_ctx *c) try
 {
     if (!c) return fail("b2f_synchronize: null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
+B2F_CATCH("b2f_synchronize")
 
-int b2f_profile_reset(b2f_ctx *c)
+int b2f_profile_reset(b2f_ctx *c) try
 {
     if (!c) return fail("b2f_profile_reset: null context");
     CHK(prof_collect(c));
@@ -740,8 +750,9 @@ int b2f_profile_reset(b2f_ctx *c)
     std::fill(c->prof_n.begin(), c->prof_n.end(), 0);
     return 0;
 }
+B2F_CATCH("b2f_profile_reset")
 
-int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launches, int cap, int *n)
+int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launches, int cap, int *n) try
 {
     if (!c || !n) return fail("b2f_profile_read: null argument");
     CHK(prof_collect(c));
@@ -754,6 +765,7 @@ int b2f_profile_read(b2f_ctx *c, char *names, double *total_ms, long long *launc
     *n = cnt;
     return 0;
 }
+B2F_CATCH("b2f_profile_read")
 
 }  // extern "C"
 
@@ -800,14 +812,15 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
 extern "C" {
 
 int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow,
-                       float *dev_occ, float *dev_est3, void *stream)
+                       float *dev_occ, float *dev_est3, void *stream) try
 {
     if (!c || !dev_in) return fail("b2f_forward_device: null argument");
     return forward_device(c, dev_in, in_kind, B, H, W, dev_flow, dev_occ, dev_est3, stream ? (hipStream_t)stream : c->stream,
                           c->use_graph != 0);
 }
+B2F_CATCH("b2f_forward_device")
 
-int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow, int cap)
+int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow, int cap) try
 {
     if (!c) return fail("b2f_output_shapes: null context");
     int no = 0;
@@ -823,8 +836,9 @@ int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow,
     }
     return 0;
 }
+B2F_CATCH("b2f_output_shapes")
 
-int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, int n_outs)
+int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, int n_outs) try
 {
     if (!c || !x || !outs) return fail("b2f_forward: null argument");
     CHK(check_shape(B, H, W));
@@ -870,6 +884,7 @@ int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, i
     cleanup();
     return rc;
 }
+B2F_CATCH("b2f_forward")
 
 // ---- op-level entry points (host pointers; reference module layouts) -----------------------
 namespace {
@@ -881,7 +896,7 @@ struct DevBuf {
 }  // namespace
 
 int b2f_op_warp_bhwd(b2f_ctx *c, const float *img, const float *grid, int B, int ih, int iw, int C, int gh,
-                     int gw, float *out)
+                     int gw, float *out) try
 {
     if (!c || !img || !grid || !out) return fail("b2f_op_warp_bhwd: null argument");
     HIPCHK(hipSetDevice(c->device));
@@ -895,8 +910,9 @@ int b2f_op_warp_bhwd(b2f_ctx *c, const float *img, const float *grid, int B, int
     HIPCHK(hipMemcpy(out, dout.p, no * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_op_warp_bhwd")
 
-int b2f_op_image_scale(b2f_ctx *c, const float *src, int C, int Hs, int Ws, int normalize, float *dst, int Hd, int Wd)
+int b2f_op_image_scale(b2f_ctx *c, const float *src, int C, int Hs, int Ws, int normalize, float *dst, int Hd, int Wd) try
 {
     if (!c || !src || !dst) return fail("b2f_op_image_scale: null argument");
     if (C <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return fail("b2f_op_image_scale: bad shape");
@@ -910,8 +926,9 @@ int b2f_op_image_scale(b2f_ctx *c, const float *src, int C, int Hs, int Ws, int 
     HIPCHK(hipMemcpy(dst, dd.p, nd * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_op_image_scale")
 
-int b2f_op_upsample_flow2x(b2f_ctx *c, const float *x, int B, int h, int w, float *y)
+int b2f_op_upsample_flow2x(b2f_ctx *c, const float *x, int B, int h, int w, float *y) try
 {
     if (!c || !x || !y) return fail("b2f_op_upsample_flow2x: null argument");
     HIPCHK(hipSetDevice(c->device));
@@ -925,9 +942,10 @@ int b2f_op_upsample_flow2x(b2f_ctx *c, const float *x, int B, int h, int w, floa
     HIPCHK(hipMemcpy(y, dy.p, 4 * n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_op_upsample_flow2x")
 
 int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, const float *nbr_past,
-                        const float *flow, float k, int B, int C, int h, int w, float *out)
+                        const float *flow, float k, int B, int C, int h, int w, float *out) try
 {
     if (!c || !ref || !nbr_future || !nbr_past || !out) return fail("b2f_op_warp_costvol: null argument");
     HIPCHK(hipSetDevice(c->device));
@@ -973,9 +991,10 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
             }
     return 0;
 }
+B2F_CATCH("b2f_op_warp_costvol")
 
 int b2f_op_costvol(b2f_ctx *c, const float *ref, const float *frm, int B, int C, int h, int w, int win, int fwd,
-                   float *out)
+                   float *out) try
 {
     if (!c || !ref || !frm || !out) return fail("b2f_op_costvol: null argument");
     if (win < 1 || win % 2 == 0) return fail("b2f_op_costvol: win must be odd");
@@ -1003,9 +1022,10 @@ int b2f_op_costvol(b2f_ctx *c, const float *ref, const float *frm, int B, int C,
     HIPCHK(hipMemcpy(out, dout.p, nout * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_op_costvol")
 
 int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, const float *wt, const float *bias,
-                   int Co, int stride, int leaky, float *y)
+                   int Co, int stride, int leaky, float *y) try
 {
     if (!c || !x || !wt || !bias || !y) return fail("b2f_op_conv3x3: null argument");
     if (stride != 1 && stride != 2) return fail("b2f_op_conv3x3: stride must be 1 or 2");
@@ -1051,5 +1071,6 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     HIPCHK(hipMemcpy(y, dyp.p, ny * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+B2F_CATCH("b2f_op_conv3x3")
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -231,6 +232,10 @@ struct b2f_ctx {
         if (e_ != hipSuccess)                                                                \
             return b2f::api_fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
+// function-try-block tail of every int-returning entry point: nothing is thrown across the C ABI
+#define B2F_CATCH(fn_)                                                                        \
+    catch (const std::exception &e_) { return b2f::api_fail(std::string(fn_ ": ") + e_.what()); } \
+    catch (...) { return b2f::api_fail(fn_ ": unknown exception"); }
 #define CHK(expr)                         \
     do {                                  \
         int rc_ = (expr);                 \

@@ -179,6 +179,16 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
         }
     };
     std::thread drainer(drain_loop);
+    struct Joiner {   // an exception on the way out (std::bad_alloc ...) must not leave the thread running
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &abort;
+        ~Joiner()
+        {
+            if (!t.joinable()) return;
+            { std::lock_guard<std::mutex> l(mu); abort = true; }
+            cv.notify_all();
+            t.join();
+        }
+    } joiner{drainer, mu, cv, abort};
 
     bool try_u8 = use_u8;             // off for the rest of the call after the first triplet that is not 8-bit data
     std::atomic<int> inexact{0};
@@ -291,22 +301,25 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
 extern "C" {
 
 int b2f_compute_flow_batch(b2f_ctx *c, int n, const float *im1, const float *im2, const float *im3, int H0,
-                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+                           int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ) try
 {
     return compute_flow_pipeline(c, n, im1, im2, im3, false, H0, W0, flow, fwd_occ, bwd_occ);
 }
+B2F_CATCH("b2f_compute_flow_batch")
 
 int b2f_compute_flow_batch_u8(b2f_ctx *c, int n, const unsigned char *im1, const unsigned char *im2,
                               const unsigned char *im3, int H0, int W0, double *flow, unsigned char *fwd_occ,
-                              unsigned char *bwd_occ)
+                              unsigned char *bwd_occ) try
 {
     return compute_flow_pipeline(c, n, im1, im2, im3, true, H0, W0, flow, fwd_occ, bwd_occ);
 }
+B2F_CATCH("b2f_compute_flow_batch_u8")
 
 int b2f_compute_flow(b2f_ctx *c, const float *im1, const float *im2, const float *im3, int H0, int W0,
-                     double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ)
+                     double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ) try
 {
     return b2f_compute_flow_batch(c, 1, im1, im2, im3, H0, W0, flow, fwd_occ, bwd_occ);
 }
+B2F_CATCH("b2f_compute_flow")
 
 }  // extern "C"
