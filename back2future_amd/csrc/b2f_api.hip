@@ -306,7 +306,8 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     // block (8 x 16 pixels) that has its CU to itself and 1.5 times as long as one that shares it with a second
     // block, so compare the number of block rounds each kernel needs on 256 CUs.
     // (B2F_WINO4_MIN_PIXELS=n: plain rule instead, F(2x2) below n pixels per map.)
-    static const int small_px = getenv("B2F_WINO4_MIN_PIXELS") ? atoi(getenv("B2F_WINO4_MIN_PIXELS")) : -1;
+    const char *small_env = getenv("B2F_WINO4_MIN_PIXELS");   // read per call: tests switch it
+    const int small_px = small_env ? atoi(small_env) : -1;
     bool alt = false;
     if (p.wino == 4) {
         if (small_px >= 0) {

@@ -186,6 +186,26 @@ def test_compute_flow_end_to_end(hard, soft, which, H, Wd):
     assert ((bo != ebo) & ~near[0:1]).sum() == 0
 
 
+@pytest.mark.parametrize("min_px", ["0", "1000000"])
+def test_compute_flow_either_winograd_kernel(hard, monkeypatch, min_px):
+    """The launcher picks F(4x4) or F(2x2) per launch by block count, which at test sizes means F(2x2) everywhere:
+    force every eligible layer of the graph onto the F(4x4) kernel (B2F_WINO4_MIN_PIXELS=0) and onto F(2x2) (1e6)."""
+    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", min_px)
+    r = _rng(12)
+    H, Wd = 128, 256
+    ims = _triplet(r, H, Wd)
+    hard.set_option("host_graph", 0)
+    try:
+        flow, fo, bo = hard.computeFlow(*ims)
+    finally:
+        hard.set_option("host_graph", 1)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
+    d = np.abs(flow - eflow)
+    assert np.abs(eflow).max() > 0.02 and d.max() <= 1e-3, d.max()
+    near = np.abs(onet - 0.6666) < 1e-3
+    assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
+
+
 def test_compute_flow_non_multiple_of_64(soft):
     """375 x 1242-style input: host-side image.scale to 320 x 1216-style size, nearest rescale back."""
     r = _rng(77)
