@@ -74,3 +74,24 @@ def test_normalize_host_mirror():
     m = np.array([0.485, 0.456, 0.406], np.float32); s = np.array([0.229, 0.224, 0.225], np.float32)
     for c in range(9):
         np.testing.assert_allclose(y[c], (np.float32(0.25) - m[c % 3]) / s[c % 3], rtol=1e-6)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "compute_flow")
+    lib_dir = os.path.join(root, "back2future_amd")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "compute_flow.c"), "-o", exe, "-L" + lib_dir, "-lb2f",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+def test_header_is_plain_c99_and_the_library_links_from_c(tmp_path):
+    """include/b2f.h must be usable from C (no C++ in the boundary): examples/compute_flow.c compiles as strict
+    C99 and links against libb2f.so; without a GPU the program fails with the library's error message."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "random:hard", "/nonexistent", "64", "64", str(tmp_path / "o")], capture_output=True)
+    assert r.returncode == 3 and b"cannot read" in r.stderr

@@ -433,3 +433,25 @@ def test_reference_sample_triplet(soft):
     assert np.abs(flow - eflow).max() <= 1e-3
     near = O.image_scale_simple((np.abs(onet - 0.6666) < 1e-3).astype(np.uint8), 375, 1242).astype(bool)
     assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
+
+
+def test_c_harness_matches_python_mirror(tmp_path, hard):
+    """examples/compute_flow.c (plain C over the C ABI, no Python / torch in the process) on a 150 x 200 triplet:
+    the same bits as the ctypes mirror."""
+    import subprocess
+    from tests.test_cabi_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = _rng(8)
+    H0, W0 = 150, 200
+    ims = _triplet(r, H0, W0)
+    np.concatenate(ims, 0).astype("<f4").tofile(str(tmp_path / "in.raw"))
+    p = subprocess.run([exe, "random:hard:5:2.0", str(tmp_path / "in.raw"), str(H0), str(W0), str(tmp_path / "out.raw")],
+                       capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    raw = np.fromfile(str(tmp_path / "out.raw"), np.uint8)
+    flow = raw[:16 * H0 * W0].view("<f8").reshape(2, H0, W0)
+    occ = raw[16 * H0 * W0:].reshape(2, 1, H0, W0)
+    eflow, efo, ebo = hard.computeFlow(*ims)
+    np.testing.assert_array_equal(flow, eflow)
+    np.testing.assert_array_equal(occ[0], efo)
+    np.testing.assert_array_equal(occ[1], ebo)
