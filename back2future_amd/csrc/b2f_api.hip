@@ -308,16 +308,21 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     // (B2F_WINO4_MIN_PIXELS=n: plain rule instead, F(2x2) below n pixels per map.)
     const char *small_env = getenv("B2F_WINO4_MIN_PIXELS");   // read per call: tests switch it
     const int small_px = small_env ? atoi(small_env) : -1;
-    bool alt = false;
+    bool alt = false, split = false;
     if (p.wino == 4) {
         if (small_px >= 0) {
             alt = H * W < small_px;
         } else {
+            // cost in twentieths of a lone F(2x2) block: F(4x4) block 60; F(2x2) block 20 alone, 40 per pair sharing a CU;
+            // F(2x2) block that computes one of the two N tiles only 13 / 26
+            const long tiles2 = (long)nimg * ((H + 7) / 8) * ((W + 15) / 16);
             const long b4 = (long)nimg * ((H + 15) / 16) * ((W + 31) / 32) * p.nblk;
-            const long b2 = (long)nimg * ((H + 7) / 8) * ((W + 15) / 16) * p.nblk2;
-            const long t4 = 3 * ((b4 + 255) / 256);
-            const long t2 = b2 <= 256 ? 1 : 2 * ((b2 + 511) / 512);
-            alt = t2 < t4;
+            const long b2 = tiles2 * p.nblk2, b2s = tiles2 * ((p.cout + 31) / 32);
+            const long t4 = 60 * ((b4 + 255) / 256);
+            const long t2 = b2 <= 256 ? 20 : 40 * ((b2 + 511) / 512);
+            const long t2s = p.nt2 != 2 ? t2 : b2s <= 256 ? 13 : 26 * ((b2s + 511) / 512);
+            alt = std::min(t2, t2s) < t4;
+            split = alt && t2s < t2;
         }
     }
     const int mode = alt ? 2 : p.wino;
@@ -342,6 +347,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.out_chunk_stride = (long)((size_t)L.Ho * L.Wo * 8);
     L.out_pix_stride = 8;
     L.nimg = nimg;
+    L.nsplit = split ? 1 : 0;
     L.leaky = leaky;
     char name[48];
     static const bool per_layer = getenv("B2F_PROFILE_LAYERS") != nullptr;   // one profile row per (layer shape, map size)
@@ -1034,7 +1040,10 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     const int chunks = (Ci + kCK - 1) / kCK, Cp = chunks * kCK;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int nt, nblk;
-    const int wino = (stride == 1 && use_wino() && Ci == 16 && Co == 16) ? 3 : stride == 1 ? wino_mode(Co) : 0;
+    int wino = (stride == 1 && use_wino() && Ci == 16 && Co == 16) ? 3 : stride == 1 ? wino_mode(Co) : 0;
+    // tests: B2F_OP_WINO_SPLIT=1 runs F(4x4)-eligible layers on the F(2x2) kernel, one block per 32-output N tile
+    const bool op_split = getenv("B2F_OP_WINO_SPLIT") && wino == 4 && Co > 32;
+    if (op_split) wino = 2;
     if (wino == 4) { nt = 2; nblk = wino4_nblk(Co); }
     else if (wino == 1 || wino == 3) { nt = 1; nblk = 1; }
     else if (wino == 2) wino_choose_tiles(Co, &nt, &nblk);
@@ -1062,6 +1071,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.wpk = dw.p; L.bias = db.p; L.out = dy.p;
     L.out_img_stride = (long)((size_t)Ho * Wo * Co); L.out_chunk_stride = 8; L.out_pix_stride = Co; L.cout = Co;
     L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
+    L.nsplit = op_split ? 1 : 0;
+    L.nb0 = 0; L.trace = nullptr;
     if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

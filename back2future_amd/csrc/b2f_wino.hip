@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // that each XCD walks a contiguous range: the n-blocks of a tile and neighbouring tiles (which share the
     // raw patch resp. its halo) run on the same XCD at about the same time and find each other's lines in L2
     int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nb = bid % p.nblk + p.nb0;
+    // split launches (NT = 2, NTV = 1, p.nsplit = 1) enumerate 32-output N tiles: n-block = index >> 1, tile nt0 = index & 1
+    const int nbx = bid % p.nblk;
+    const int nt0 = (NT == 2 && NTV == 1) ? (nbx & p.nsplit) : 0;
+    const int nb = (nbx >> ((NT == 2 && NTV == 1) ? p.nsplit : 0)) + p.nb0;
     bid /= p.nblk;
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) acc[x][nt][r] = 0.f;
 
     const int a_off = (4 * wave * 2 + half) * 32 + m;                    // V[xi = 4w][k4 = half][tile m]; xi+1 -> +64
-    const unsigned b_off = ((4 * wave * 2 + half) * NB + m) * 16u;       // bytes: U[xi = 4w][k4 = half][co m]; xi+1 -> +2*NB*16
+    const unsigned b_off = ((4 * wave * 2 + half) * NB + nt0 * 32 + m) * 16u;       // bytes: U[xi = 4w][k4 = half][co m]; xi+1 -> +2*NB*16
     f32x4 b0[2 * NTV], b1[2 * NTV];
 
     // ---- prologue: raw(0), raw(1) and the first B pair in flight together ----
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int it = 0; it < NTV; ++it) {
         const int idx = tid + it * 256;
         const int o_cq = idx % (NTV * 8), o_t = idx / (NTV * 8);
-        const int co0 = nb * NB + 4 * o_cq;
+        const int co0 = nb * NB + nt0 * 32 + 4 * o_cq;
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
         f32x4 mm[4][2];
 #pragma unroll
@@ -356,6 +359,7 @@ static hipError_t launch_wino_t(const ConvLaunch &p, int nb0, int nblk, hipStrea
     }
     ConvLaunch q = p;
     q.nb0 = nb0;
+    q.nsplit = (NT == 2 && NTV == 1) ? p.nsplit : 0;
     q.trace = nullptr;
 #if B2F_WINO_TRACE
     static long long *trace_dev = nullptr;
@@ -399,6 +403,7 @@ hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s)
         if ((double)p.H * p.W * p.seg[i].pix_stride * 4.0 >= 4294967296.0) return hipErrorInvalidValue;
     if (p.nt == 1) return launch_wino_t<1, 1>(p, 0, p.nblk, s);
     if (p.nt != 2) return hipErrorInvalidValue;
+    if (p.nsplit) return launch_wino_t<2, 1>(p, 0, (p.cout + 31) / 32, s);   // one block per 32 outputs
     // n-blocks whose two N tiles both hold real channels, then the half-empty last one (cout = 96)
     const int nfull = p.cout / 64, part = (p.cout % 64) ? 1 : 0;
     const bool part_full = (p.cout % 64) > 32;

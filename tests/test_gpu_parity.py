@@ -66,6 +66,18 @@ def test_conv3x3(hard, ci, co, stride, h, w, leaky):
         np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 16, 30), (96, 64, 9, 17), (40, 96, 33, 20), (264, 128, 8, 16), (64, 68, 7, 9)])
+def test_conv3x3_f2x2_one_n_tile_per_block(hard, monkeypatch, ci, co, h, w):
+    """The F(2x2) kernel launched with one block per 32-output N tile (what small launches of wide layers use)."""
+    monkeypatch.setenv("B2F_OP_WINO_SPLIT", "1")
+    r = _rng(ci + co)
+    x = r.standard_normal((3, ci, h, w), dtype=np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = r.standard_normal(co, dtype=np.float32)
+    got = ops.conv3x3(hard, x, wt, b, 1, True)
+    np.testing.assert_allclose(got, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=3e-5)
+
+
 def test_conv3x3_transpose_detecting(hard):
     """asymmetric single-tap kernels: catches swapped rows/cols, taps or channels."""
     x = np.arange(2 * 8 * 6 * 10, dtype=np.float32).reshape(2, 8, 6, 10) / 100
