@@ -459,7 +459,9 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.out_pix_stride = 8;
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
         {
-            Scope sc(c, s, "warp_costvol", cap);
+            char cname[48];
+            snprintf(cname, sizeof cname, getenv("B2F_PROFILE_LAYERS") ? "warp_costvol_%dx%d" : "warp_costvol", h, w);
+            Scope sc(c, s, cname, cap);
             HIPCHK(launch_warp_costvol(cl, s));
         }
         // occlusion decoder + SpatialSoftMax + nearest x4 (pwc.lua:288-321); dead below level 3 unless full

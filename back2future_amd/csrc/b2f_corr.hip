@@ -75,8 +75,12 @@ __device__ __forceinline__ void top_left(float coord, int size, int &pt, float &
 // with the natural order the 3x halo overlap of neighbouring tiles is re-fetched from the fabric
 // by up to 8 different L2s.  Give every XCD one contiguous band of tiles instead (bijective for
 // any grid size; placement only affects speed, never results).
-template <bool POW2>
-__global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p)
+// LAT: variant for launches that cannot fill the chip anyway (a single triplet, the coarse levels): two blocks per CU
+// instead of three buy the registers to issue all 24 gather loads of a chunk at once -- one memory round trip per
+// chunk instead of three, which is most of what a lone block's run time consists of.  (Also tried: one block per CU
+// with the next chunk's loads issued before the FMA phase -- slower, the 96 extra live registers go through AGPRs.)
+template <bool POW2, bool LAT>
+__global__ __launch_bounds__(256, LAT ? 2 : 3) void warp_costvol_kernel(const CorrLaunch p)
 {
     __shared__ __attribute__((aligned(16))) float4 nb[2][2][HH * HP];   // [map][k4][pixel] 32 KB
     __shared__ float4 samp_w[2][NHALO];                                  // 12 KB
@@ -154,37 +158,74 @@ __global__ __launch_bounds__(256, 3) void warp_costvol_kernel(const CorrLaunch p
         // 2 maps x 384 halo pixels = 768 = 3 per thread; a thread fetches both float4 of the chunk
         // for its halo pixel (the sampling record, its only per-pixel state, lives in LDS), 8 loads
         // in flight, blend = 1 mul + 3 fma per component.
+        if constexpr (!LAT) {
 #pragma unroll 1
-        for (int j = 0; j < 3; ++j) {
-            const int q = tid + j * 256;
-            const int map = q >= NHALO;
-            const float4 wg = (&samp_w[0][0])[q];
-            const SampIdx si = (&samp_i[0][0])[q];
-            const float *src = nbr[map] + coff + si.idx;
-            const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
-            float4 t[8];
-            if (!(p.ablate & 1)) {
+            for (int j = 0; j < 3; ++j) {
+                const int q = tid + j * 256;
+                const int map = q >= NHALO;
+                const float4 wg = (&samp_w[0][0])[q];
+                const SampIdx si = (&samp_i[0][0])[q];
+                const float *src = nbr[map] + coff + si.idx;
+                const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
+                float4 t[8];
+                if (!(p.ablate & 1)) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 2; ++k4) {
+                        t[k4 * 4 + 0] = *reinterpret_cast<const float4 *>(src + 4 * k4);
+                        t[k4 * 4 + 1] = *reinterpret_cast<const float4 *>(src + dx + 4 * k4);
+                        t[k4 * 4 + 2] = *reinterpret_cast<const float4 *>(src + dy + 4 * k4);
+                        t[k4 * 4 + 3] = *reinterpret_cast<const float4 *>(src + dy + dx + 4 * k4);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = wg;
+                }
+                float4 *dst = &nb[map][0][si.flags >> 2];
 #pragma unroll
                 for (int k4 = 0; k4 < 2; ++k4) {
-                    t[k4 * 4 + 0] = *reinterpret_cast<const float4 *>(src + 4 * k4);
-                    t[k4 * 4 + 1] = *reinterpret_cast<const float4 *>(src + dx + 4 * k4);
-                    t[k4 * 4 + 2] = *reinterpret_cast<const float4 *>(src + dy + 4 * k4);
-                    t[k4 * 4 + 3] = *reinterpret_cast<const float4 *>(src + dy + dx + 4 * k4);
+                    const float4 tl = t[k4 * 4], tr = t[k4 * 4 + 1], bl = t[k4 * 4 + 2], br = t[k4 * 4 + 3];
+                    float4 v;
+                    v.x = fmaf(wg.w, br.x, fmaf(wg.z, bl.x, fmaf(wg.y, tr.x, wg.x * tl.x)));
+                    v.y = fmaf(wg.w, br.y, fmaf(wg.z, bl.y, fmaf(wg.y, tr.y, wg.x * tl.y)));
+                    v.z = fmaf(wg.w, br.z, fmaf(wg.z, bl.z, fmaf(wg.y, tr.z, wg.x * tl.z)));
+                    v.w = fmaf(wg.w, br.w, fmaf(wg.z, bl.w, fmaf(wg.y, tr.w, wg.x * tl.w)));
+                    dst[k4 * (HH * HP)] = v;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = wg;
             }
-            float4 *dst = &nb[map][0][si.flags >> 2];
+        } else {
+            float4 tt[3][8], wgs[3];
+            int slot[3];
 #pragma unroll
-            for (int k4 = 0; k4 < 2; ++k4) {
-                const float4 tl = t[k4 * 4], tr = t[k4 * 4 + 1], bl = t[k4 * 4 + 2], br = t[k4 * 4 + 3];
-                float4 v;
-                v.x = fmaf(wg.w, br.x, fmaf(wg.z, bl.x, fmaf(wg.y, tr.x, wg.x * tl.x)));
-                v.y = fmaf(wg.w, br.y, fmaf(wg.z, bl.y, fmaf(wg.y, tr.y, wg.x * tl.y)));
-                v.z = fmaf(wg.w, br.z, fmaf(wg.z, bl.z, fmaf(wg.y, tr.z, wg.x * tl.z)));
-                v.w = fmaf(wg.w, br.w, fmaf(wg.z, bl.w, fmaf(wg.y, tr.w, wg.x * tl.w)));
-                dst[k4 * (HH * HP)] = v;
+            for (int j = 0; j < 3; ++j) {
+                const int q = tid + j * 256;
+                const int map = q >= NHALO;
+                wgs[j] = (&samp_w[0][0])[q];
+                const SampIdx si = (&samp_i[0][0])[q];
+                const float *src = nbr[map] + coff + si.idx;
+                const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
+                slot[j] = map * (2 * HH * HP) + (si.flags >> 2);
+#pragma unroll
+                for (int k4 = 0; k4 < 2; ++k4) {
+                    tt[j][k4 * 4 + 0] = *reinterpret_cast<const float4 *>(src + 4 * k4);
+                    tt[j][k4 * 4 + 1] = *reinterpret_cast<const float4 *>(src + dx + 4 * k4);
+                    tt[j][k4 * 4 + 2] = *reinterpret_cast<const float4 *>(src + dy + 4 * k4);
+                    tt[j][k4 * 4 + 3] = *reinterpret_cast<const float4 *>(src + dy + dx + 4 * k4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 wg = wgs[j];
+                float4 *dst = &nb[0][0][0] + slot[j];
+#pragma unroll
+                for (int k4 = 0; k4 < 2; ++k4) {
+                    const float4 tl = tt[j][k4 * 4], tr = tt[j][k4 * 4 + 1], bl = tt[j][k4 * 4 + 2], br = tt[j][k4 * 4 + 3];
+                    float4 v;
+                    v.x = fmaf(wg.w, br.x, fmaf(wg.z, bl.x, fmaf(wg.y, tr.x, wg.x * tl.x)));
+                    v.y = fmaf(wg.w, br.y, fmaf(wg.z, bl.y, fmaf(wg.y, tr.y, wg.x * tl.y)));
+                    v.z = fmaf(wg.w, br.z, fmaf(wg.z, bl.z, fmaf(wg.y, tr.z, wg.x * tl.z)));
+                    v.w = fmaf(wg.w, br.w, fmaf(wg.z, bl.w, fmaf(wg.y, tr.w, wg.x * tl.w)));
+                    dst[k4 * (HH * HP)] = v;
+                }
             }
         }
         // reference pixel chunk (address is clamped to a valid pixel for out-of-image lanes)
@@ -273,8 +314,17 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * p.B));
-    if (pow2) hipLaunchKernelGGL(warp_costvol_kernel<true>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(warp_costvol_kernel<false>, grid, dim3(256), 0, s, p);
+    // at most one round of two blocks per CU: the latency variant (B2F_CORR_LAT=0|1 forces either)
+    const char *lat_s = getenv("B2F_CORR_LAT");   // read per call: tests switch it
+    const int lat_env = lat_s ? atoi(lat_s) : -1;
+    const bool lat = lat_env >= 0 ? lat_env != 0 : grid.x <= 512 && !ablate;
+    if (lat) {
+        if (pow2) hipLaunchKernelGGL((warp_costvol_kernel<true, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_kernel<false, true>), grid, dim3(256), 0, s, p);
+    } else {
+        if (pow2) hipLaunchKernelGGL((warp_costvol_kernel<true, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_kernel<false, false>), grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 

@@ -96,8 +96,16 @@ def test_conv3x3_transpose_detecting(hard):
         np.testing.assert_allclose(got, O.conv3x3(x, wt, np.zeros(68, np.float32), 1, False), rtol=0, atol=2e-5)
 
 
+@pytest.fixture(params=["0", "1"], ids=["corr-regular", "corr-latency-variant"])
+def corr_variant(request, monkeypatch):
+    """Both instantiations of the warp + cost-volume kernel (the launcher would pick the latency variant for every
+    test-sized launch)."""
+    monkeypatch.setenv("B2F_CORR_LAT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("C,h,w", [(32, 24, 40), (192, 4, 7), (96, 9, 17), (8, 1, 2), (64, 16, 16)])
-def test_costvol_no_warp(hard, C, h, w):
+def test_costvol_no_warp(hard, corr_variant, C, h, w):
     r = _rng(C + h)
     ref = r.standard_normal((2, C, h, w), dtype=np.float32)
     frm = r.standard_normal((2, C, h, w), dtype=np.float32)
@@ -130,7 +138,7 @@ def test_costvol_impulse_known_answer(hard):
 
 
 @pytest.mark.parametrize("C,h,w,k", [(32, 24, 40, 2.5), (128, 8, 14, 0.625), (64, 16, 30, 5.0)])
-def test_warp_costvol_fused(hard, C, h, w, k):
+def test_warp_costvol_fused(hard, corr_variant, C, h, w, k):
     """fused kernel == warpingUnit x2 + CostVolMulti x2 + JoinTable of the oracle."""
     r = _rng(C * 7 + h)
     ref = r.standard_normal((2, C, h, w), dtype=np.float32)
@@ -178,7 +186,7 @@ def _triplet(r, H, W):
 
 
 @pytest.mark.parametrize("which,H,Wd", [("hard", 128, 192), ("soft", 128, 192), ("soft", 64, 64), ("hard", 192, 320)])
-def test_compute_flow_end_to_end(hard, soft, which, H, Wd):
+def test_compute_flow_end_to_end(hard, soft, corr_variant, which, H, Wd):
     """computeFlow (flow, fwd_occ, bwd_occ) on a /64 input: HIP path vs oracle.
     Bar: max-abs(flow) <= 1e-3, EPE <= 1e-3 (BASELINE.json); masks may differ only where
     est[3] is within 1e-3 of the 0.6666 threshold."""
