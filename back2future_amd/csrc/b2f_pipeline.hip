@@ -12,19 +12,23 @@ static int fail(const std::string &m) { return api_fail(m); }
 // ---- host-buffer entry point: a double-buffered upload / compute / download pipeline ----------------
 namespace {
 
-// true when [p, p + bytes) is page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister,
-// e.g. a torch pin_memory() tensor): such buffers are DMA'd directly, pageable ones go through the pinned slot
-bool is_pinned(const void *p, size_t bytes)
+// 1 when [p, p + bytes) is page-locked host memory known to the HIP runtime (hipHostMalloc / hipHostRegister, e.g. a
+// torch pin_memory() tensor): such buffers are DMA'd directly; 0 for ordinary (pageable) host memory, which goes
+// through the pinned slot; -1 for device / managed memory, which the host entry points refuse
+int mem_kind(const void *p, size_t bytes)
 {
+    int kind = 1;
     for (const char *q : {(const char *)p, (const char *)p + bytes - 1}) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, q) != hipSuccess) {
             (void)hipGetLastError();
-            return false;
+            kind = 0;
+            continue;
         }
-        if (a.type != hipMemoryTypeHost) return false;
+        if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeArray) return -1;
+        if (a.type != hipMemoryTypeHost) kind = 0;
     }
-    return true;
+    return kind;
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -126,10 +130,15 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
 
     if (!c->s_in) HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     if (!c->s_out) HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    const bool pinned_in = is_pinned(im1, (size_t)n * 3 * hw0 * esz) && is_pinned(im2, (size_t)n * 3 * hw0 * esz) &&
-                           is_pinned(im3, (size_t)n * 3 * hw0 * esz);
+    const int k_in[3] = {mem_kind(im1, (size_t)n * 3 * hw0 * esz), mem_kind(im2, (size_t)n * 3 * hw0 * esz),
+                         mem_kind(im3, (size_t)n * 3 * hw0 * esz)};
+    const int k_out[3] = {mem_kind(flow, (size_t)n * 2 * hw0 * 8), mem_kind(fwd_occ, (size_t)n * hw0), mem_kind(bwd_occ, (size_t)n * hw0)};
+    for (int i = 0; i < 3; ++i)
+        if (k_in[i] < 0 || k_out[i] < 0)
+            return fail("b2f_compute_flow: device memory passed to a host-buffer entry point (use b2f_forward_device)");
+    const bool pinned_in = k_in[0] == 1 && k_in[1] == 1 && k_in[2] == 1;
     const bool stage_in = !pinned_in && !bytes_in;   // float staging buffer (byte inputs stage through h_u8)
-    const bool stage_masks = !(is_pinned(fwd_occ, (size_t)n * hw0) && is_pinned(bwd_occ, (size_t)n * hw0));
+    const bool stage_masks = !(k_out[1] == 1 && k_out[2] == 1);
     for (int k = 0; k < std::min(nsub, 2); ++k)
         CHK(ensure_slot(c, c->slot[k], SB, hw0, hw, H0, fw, same, C3, stage_in, stage_masks, use_u8));
     // the calling thread and the drain thread each count as one worker of their pool

@@ -382,6 +382,21 @@ def test_graph_replay_matches_eager(soft):
         np.testing.assert_array_equal(o, outs[0][1])
 
 
+def test_host_entry_point_refuses_device_memory(hard):
+    import ctypes as C
+    import torch
+    from back2future_amd import _lib
+    from back2future_amd._lib import B2FError
+    x = torch.rand(3, 64, 64, device="cuda")
+    flow = np.empty((2, 64, 64), np.float64); fo = np.empty((64, 64), np.uint8); bo = np.empty((64, 64), np.uint8)
+    fp = C.cast(x.data_ptr(), _lib.c_float_p)
+    rc = _lib.lib().b2f_compute_flow(hard._h, fp, fp, fp, 64, 64, flow.ctypes.data_as(C.POINTER(C.c_double)),
+                                     fo.ctypes.data_as(C.POINTER(C.c_ubyte)), bo.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    assert rc != 0
+    with pytest.raises(B2FError, match="device memory"):
+        _lib.check(rc)
+
+
 def test_errors_are_loud(hard):
     from back2future_amd._lib import B2FError
     with pytest.raises(B2FError, match="cannot open"):
