@@ -220,22 +220,26 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
                         HIPCHK(hipMemcpyAsync(du + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0, hipMemcpyHostToDevice, c->s_in));
                 } else {
                     unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
-                    std::vector<CopyJob> jobs;
-                    for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0});
-                    c->pool_in->run(jobs);
-                    HIPCHK(hipMemcpyAsync(du, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
+                    for (int f = 0; f < 3; ++f) {   // frame by frame: the DMA of one frame runs under the staging copy of the next
+                        c->pool_in->run({{st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0, 3 * hw0}});
+                        HIPCHK(hipMemcpyAsync(du + (size_t)f * 3 * hw0, st + (size_t)f * 3 * hw0, 3 * hw0, hipMemcpyHostToDevice, c->s_in));
+                    }
                 }
                 as_u8[t] = 1;
                 continue;
             }
             if (try_u8) {
                 unsigned char *st = hs.h_u8 + (size_t)t * 9 * hw0;
-                std::vector<CopyJob> jobs;
-                for (int f = 0; f < 3; ++f)
-                    jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact});
-                c->pool_in->run(jobs);
+                // frame by frame: the DMA of a packed frame runs under the packing of the next.  A frame that turns
+                // out not to be 8-bit data sends the whole triplet down the float path (its earlier frames are
+                // uploaded twice; d_up is what the kernels read for it).
+                for (int f = 0; f < 3 && !inexact.load(); ++f) {
+                    c->pool_in->run({{st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, JOB_PACK_U8, 1.0, &inexact}});
+                    if (!inexact.load())
+                        HIPCHK(hipMemcpyAsync(hs.d_u8 + ((size_t)t * 9 + (size_t)f * 3) * hw0, st + (size_t)f * 3 * hw0, 3 * hw0,
+                                              hipMemcpyHostToDevice, c->s_in));
+                }
                 if (!inexact.load()) {
-                    HIPCHK(hipMemcpyAsync(hs.d_u8 + (size_t)t * 9 * hw0, st, 9 * hw0, hipMemcpyHostToDevice, c->s_in));
                     as_u8[t] = 1;
                     continue;
                 }
@@ -243,10 +247,10 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
             }
             if (stage_in) {
                 float *st = hs.h_in + (size_t)t * 9 * hw0;
-                std::vector<CopyJob> jobs;
-                for (int f = 0; f < 3; ++f) jobs.push_back({st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4});
-                c->pool_in->run(jobs);
-                HIPCHK(hipMemcpyAsync(dst, st, 9 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
+                for (int f = 0; f < 3; ++f) {
+                    c->pool_in->run({{st + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4}});
+                    HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, st + (size_t)f * 3 * hw0, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
+                }
             } else {
                 for (int f = 0; f < 3; ++f)
                     HIPCHK(hipMemcpyAsync(dst + (size_t)f * 3 * hw0, ims[f] + (b0 + t) * 3 * hw0 * 4, 3 * hw0 * 4, hipMemcpyHostToDevice, c->s_in));
