@@ -1,0 +1,63 @@
+"""Soak test of the host-buffer entry points on the GPU box: random shapes (also not multiples of 64), batch sizes,
+input kinds (floats, k/255 floats, bytes; pageable or page-locked), sub-batch settings and graph replay on/off, each
+result checked against the same triplets computed one at a time, device memory watched for growth.
+    python tools/soak.py [iterations] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from back2future_amd import back2future  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    r = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    os.environ["B2F_WINO4_MIN_PIXELS"] = "4096"      # kernel choice independent of the batch: bit-identical results
+    models = {"hard": back2future.Model("random:hard:3:2.0"), "soft": back2future.Model("random:soft:3:2.0")}
+    free0 = None
+    t0 = time.time()
+    for it in range(iters):
+        m = models["hard" if r.integers(2) else "soft"]
+        H0, W0 = int(r.integers(64, 300)), int(r.integers(64, 420))
+        n = int(r.integers(1, 7))
+        kind = int(r.integers(3))                   # 0 floats, 1 k/255 floats, 2 bytes
+        pinned = bool(r.integers(2))
+        os.environ["B2F_HOST_SUBBATCH_PIXELS"] = str(int(r.choice([H0 * W0, 3 * H0 * W0, 1 << 24])))
+        os.environ["B2F_HOST_THREADS"] = str(int(r.choice([2, 5, 16])))
+        m.set_option("host_graph", int(r.integers(2)))
+        by = r.integers(0, 256, (3, n, 3, H0, W0), dtype=np.uint8)
+        if kind == 2:
+            ims = [by[i] for i in range(3)]
+        elif kind == 1:
+            ims = [(by[i].astype(np.float32) / np.float32(255.0)).astype(np.float32) for i in range(3)]
+        else:
+            ims = [r.random((n, 3, H0, W0), dtype=np.float32) for _ in range(3)]
+        if pinned:
+            keep = [torch.from_numpy(a).pin_memory() for a in ims]
+            ims = [t.numpy() for t in keep]
+        flow, fo, bo = m.computeFlowBatch(*ims)
+        assert np.isfinite(flow).all()
+        for i in set(int(x) for x in r.integers(0, n, 2)):
+            one = [a[i:i + 1] for a in ims]
+            f1, fo1, bo1 = m.computeFlowBatch(*one)
+            assert np.array_equal(f1[0], flow[i]) and np.array_equal(fo1[0], fo[i]) and np.array_equal(bo1[0], bo[i]), \
+                (it, H0, W0, n, kind, pinned, i)
+        if it == 20:
+            free0 = torch.cuda.mem_get_info()[0]
+        if it % 25 == 0:
+            print("it %d  %dx%d n=%d kind=%d pinned=%d  free %.2f GB  %.0f s" % (it, H0, W0, n, kind, pinned,
+                  torch.cuda.mem_get_info()[0] / 2**30, time.time() - t0), flush=True)
+    free1 = torch.cuda.mem_get_info()[0]
+    print("done: %d iterations, device memory after warm-up %.2f GB free -> %.2f GB free" % (iters, free0 / 2**30, free1 / 2**30))
+    assert free0 - free1 < (2 << 30), "device memory keeps growing"
+    for m in models.values():
+        m.close()
+
+
+if __name__ == "__main__":
+    main()
