@@ -271,14 +271,20 @@ namespace {
 int ensure_workspace(b2f_ctx *c, const Plan &p)
 {
     if (p.total > c->arena_floats) {
+        // rare (a larger shape than any before): full device syncs on both sides.  Earlier passes may have run on a
+        // caller's stream, and hipMemset is asynchronous on the null stream, which the non-blocking streams the
+        // kernels run on do not wait for -- without the second sync the memset could land on top of the first
+        // kernels' output (found by tools/soak.py).
         if (c->arena) {
-            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipFree(c->arena));
             c->arena = nullptr;
+            c->arena_floats = 0;
             drop_graphs(c);
         }
         HIPCHK(hipMalloc(&c->arena, p.total * sizeof(float)));
         HIPCHK(hipMemset(c->arena, 0, p.total * sizeof(float)));
+        HIPCHK(hipDeviceSynchronize());
         c->arena_floats = p.total;
     }
     return 0;

@@ -45,8 +45,16 @@ def main():
         for i in set(int(x) for x in r.integers(0, n, 2)):
             one = [a[i:i + 1] for a in ims]
             f1, fo1, bo1 = m.computeFlowBatch(*one)
-            assert np.array_equal(f1[0], flow[i]) and np.array_equal(fo1[0], fo[i]) and np.array_equal(bo1[0], bo[i]), \
-                (it, H0, W0, n, kind, pinned, i)
+            if not (np.array_equal(f1[0], flow[i]) and np.array_equal(fo1[0], fo[i]) and np.array_equal(bo1[0], bo[i])):
+                d = np.abs(f1[0] - flow[i])
+                print("MISMATCH it %d %dx%d n=%d kind=%d pinned=%d triplet %d: max|dflow| %.3g at %s (%d values differ), masks differ %d / %d; env %s graph %s"
+                      % (it, H0, W0, n, kind, pinned, i, d.max(), np.unravel_index(d.argmax(), d.shape), int((d > 0).sum()),
+                         int((fo1[0] != fo[i]).sum()), int((bo1[0] != bo[i]).sum()),
+                         {k: v for k, v in os.environ.items() if k.startswith("B2F_")}, "?"), flush=True)
+                again = m.computeFlowBatch(*ims)
+                print("   batch recomputed equals first batch result:", np.array_equal(again[0], flow), " single recomputed equals single:",
+                      np.array_equal(m.computeFlowBatch(*one)[0], f1), flush=True)
+                raise SystemExit(1)
         if it == 20:
             free0 = torch.cuda.mem_get_info()[0]
         if it % 25 == 0:
