@@ -490,3 +490,25 @@ def test_c_harness_matches_python_mirror(tmp_path, hard):
     np.testing.assert_array_equal(flow, eflow)
     np.testing.assert_array_equal(occ[0], efo)
     np.testing.assert_array_equal(occ[1], ebo)
+
+
+def test_growing_shapes_match_a_fresh_context(monkeypatch):
+    """A long-lived context whose workspace arena, buffer sets and graph cache keep growing must give the bits a
+    fresh context gives for every shape (regression: the arena used to be zeroed by an asynchronous null-stream
+    memset that could land on top of the first kernels' output after it grew)."""
+    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", "4096")     # kernel choice by map size only
+    r = _rng(77)
+    old = back2future.Model("random:soft:4:2.0")
+    try:
+        for n, H0, W0 in [(1, 64, 64), (2, 100, 180), (3, 128, 256), (4, 200, 300), (5, 264, 374), (6, 320, 448), (2, 70, 90)]:
+            ims = [r.random((n, 3, H0, W0), dtype=np.float32) for _ in range(3)]
+            got = old.computeFlowBatch(*ims)
+            fresh = back2future.Model("random:soft:4:2.0")
+            try:
+                exp = fresh.computeFlowBatch(*ims)
+            finally:
+                fresh.close()
+            for a, b in zip(got, exp):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        old.close()
