@@ -1,0 +1,71 @@
+"""GPU: the BASELINE.json configurations at their full sizes.  The oracle needs seconds per full-HD triplet on the GPU
+box's host cores, so one triplet of every batch is compared against it (the end-to-end bar: max-abs <= 1e-3); the
+whole batch is checked through size-independent properties of the path: determinism, batch-permutation equivariance
+(triplets are independent), single pass == batched pass, the occlusion softmax summing to one, and -- at the boundary
+-- the host-buffer entry point against the device-pointer one."""
+import numpy as np
+import pytest
+
+from back2future_amd import back2future, weights as W
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MEAN = np.array([0.485, 0.456, 0.406] * 3, np.float32).reshape(1, 9, 1, 1)
+STD = np.array([0.229, 0.224, 0.225] * 3, np.float32).reshape(1, 9, 1, 1)
+
+
+def _run(torch, m, x):
+    B, _, H, Wd = x.shape
+    torch.cuda.synchronize()          # x was produced on torch's stream; the context runs on its own non-blocking stream
+    flow = torch.empty(B, 2, H, Wd, device="cuda")
+    occ = torch.empty(B, 2, H, Wd, device="cuda")
+    est3 = torch.empty(B, 2 if m.past_flow else 3, H, Wd, device="cuda")
+    m.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), occ.data_ptr(), est3.data_ptr(), unit_input=True)
+    m.synchronize()
+    return flow, occ, est3
+
+
+# BASELINE.json configs[1..4] (the last one is the per-GPU share, 16 triplets, of the 8-GPU batch of 128)
+@pytest.mark.parametrize("which,B,H,Wd", [("hard", 8, 256, 512), ("soft", 32, 384, 1280), ("soft", 8, 448, 1024), ("hard", 16, 1024, 1920)])
+def test_baseline_config_full_size(monkeypatch, which, B, H, Wd):
+    import torch
+    import bench
+    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", "4096")      # Winograd variant per map size only: passes of any batch size agree bit for bit
+    past = which == "soft"
+    m = back2future.Model("random:%s:2:1.0" % which)
+    try:
+        x = bench.make_triplets(torch, B, H, Wd, seed=11, device=torch.device("cuda", 0))
+        torch.cuda.synchronize()
+        flow, occ, est3 = _run(torch, m, x)
+        assert bool(torch.isfinite(flow).all() and torch.isfinite(occ).all() and torch.isfinite(est3).all())
+        assert float(flow.abs().max()) > 1e-3
+        # occlusion probabilities: softmax over two channels (pwc.lua:308)
+        assert float((occ.sum(1) - 1).abs().max()) <= 1e-6 and float(occ.min()) >= 0
+        # determinism
+        for a, b in zip(_run(torch, m, x), (flow, occ, est3)):
+            assert torch.equal(a, b)
+        # triplets are independent: a permuted batch gives the permuted outputs, one triplet alone gives its slice
+        perm = torch.arange(B - 1, -1, -1, device="cuda")
+        for a, b in zip(_run(torch, m, x[perm].contiguous()), (flow, occ, est3)):
+            assert torch.equal(a, b[perm])
+        i = B // 3
+        for a, b in zip(_run(torch, m, x[i:i + 1].contiguous()), (flow, occ, est3)):
+            assert torch.equal(a[0], b[i])
+        # that triplet against the oracle (full graph; est[1] = flow, then occ / past flow by model shape, pwc.lua:459-489)
+        xn = ((x[i:i + 1].cpu().numpy() + (-MEAN)) / STD).astype(np.float32)
+        table = O.pwc_forward(xn, W.random_init(2, past, 1.0), past)
+        eflow, eocc = table[0][0], table[2 if past else 1][0]
+        d = np.abs(flow[i].cpu().numpy() - eflow)
+        epe = float(np.sqrt(((flow[i].cpu().numpy() - eflow) ** 2).sum(0)).mean())
+        assert d.max() <= 1e-3 and epe <= 1e-3, (d.max(), epe)
+        assert np.abs(occ[i].cpu().numpy() - eocc).max() <= 1e-3
+        # the host-buffer boundary on the same triplet: same network outputs behind computeFlow's post-processing
+        ims = [np.ascontiguousarray(x[i, 3 * f:3 * f + 3].cpu().numpy()) for f in range(3)]
+        cflow, fo, bo = m.computeFlow(*ims)
+        np.testing.assert_array_equal(cflow, flow[i].cpu().numpy().astype(np.float64))
+        e3 = est3[i].cpu().numpy().astype(np.float64)
+        np.testing.assert_array_equal(fo[0], (e3[1] >= 0.6666).astype(np.uint8))
+        np.testing.assert_array_equal(bo[0], (e3[0] >= 0.6666).astype(np.uint8))
+    finally:
+        m.close()
