@@ -239,6 +239,7 @@ def main():
     occ = torch.empty(B, 2, H, W, device=dev)
     est3 = torch.empty(B, 3, H, W, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()   # x is produced on torch's stream; stream 0 selects the context's own non-blocking stream
 
     def step():
         model.forward_device(x.data_ptr(), B, H, W, flow.data_ptr(), occ.data_ptr(), est3.data_ptr(),
