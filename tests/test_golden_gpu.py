@@ -42,6 +42,7 @@ def test_forward_golden(kind):
     flow = torch.zeros(B, 2, H, W, device="cuda")
     occ = torch.zeros(B, 2, H, W, device="cuda")
     est3 = torch.zeros(B, 2 if past else 3, H, W, device="cuda")
+    torch.cuda.synchronize()                       # the fills run on torch's stream, the context on its own
     m.forward_device(x.data_ptr(), B, H, W, flow.data_ptr(), occ.data_ptr(), est3.data_ptr())
     m.synchronize()
     assert np.abs(flow.cpu().numpy() - g["out00"]).max() <= 1e-3

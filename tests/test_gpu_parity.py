@@ -373,6 +373,7 @@ def test_graph_replay_matches_eager(soft):
     for use_graph in (0, 1, 1, 1):        # eager; first sight (eager); capture + replay; replay
         soft.set_option("use_graph", use_graph)
         flow = torch.zeros(B, 2, H, Wd, device="cuda"); occ = torch.zeros(B, 2, H, Wd, device="cuda")
+        torch.cuda.synchronize()                   # the fills run on torch's stream, the context on its own
         soft.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), occ.data_ptr())
         soft.synchronize()
         outs.append((flow.cpu().numpy(), occ.cpu().numpy()))
