@@ -647,7 +647,9 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
     }
     b2f_ctx *c = new b2f_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    // a blocking stream: ordered with the legacy default stream like any such stream, so inputs that PyTorch (whose
+    // default stream is the null stream) or hipMemcpy / hipMemset produced there are complete before our kernels read them
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
         delete c;
         return fail("b2f_init: hipStreamCreate failed");
     }

@@ -116,9 +116,9 @@ B2F_API int b2f_compute_flow_batch_u8(b2f_ctx *ctx, int n, const unsigned char *
  *   dev_occ   B x 2 x H x W   skip_occs[3] (softmax probabilities)
  *   dev_est3  B x C3 x H x W  est[3] as computeFlow reads it: C3 = 2 (Soft: the
  *                             occlusion map) or 3 (Hard: warped image 1)
- * The call is asynchronous on `stream`; the context's own stream (NULL) is non-blocking, i.e.
- * not ordered with the default stream: inputs must be complete, results are awaited with
- * b2f_synchronize.                                            */
+ * The call is asynchronous on `stream`; the context's own stream (NULL) is a blocking stream
+ * (ordered with the legacy default stream, not with other non-blocking streams); results are
+ * awaited with b2f_synchronize.                                            */
 enum { B2F_IN_NORMALIZED = 0, B2F_IN_UNIT = 1 };
 B2F_API int b2f_forward_device(b2f_ctx *ctx, const void *dev_in, int in_kind, int B, int H, int W,
                        float *dev_flow, float *dev_occ, float *dev_est3, void *stream);

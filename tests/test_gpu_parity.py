@@ -513,3 +513,25 @@ def test_growing_shapes_match_a_fresh_context(monkeypatch):
                 np.testing.assert_array_equal(a, b)
     finally:
         old.close()
+
+
+def test_context_stream_is_ordered_with_the_default_stream(hard):
+    """Inputs produced on the default stream right before b2f_forward_device(stream = NULL), no synchronization in
+    between: the context's stream is a blocking one, so it must see the finished inputs."""
+    import torch
+    B, H, Wd = 2, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.rand((B, 9, H, Wd), generator=g, device="cuda")
+    torch.cuda.synchronize()
+    flow_ref = torch.empty(B, 2, H, Wd, device="cuda")
+    hard.forward_device(base.data_ptr(), B, H, Wd, flow_ref.data_ptr(), unit_input=True)
+    hard.synchronize()
+    for _ in range(5):
+        big = torch.rand((64, 1024, 1024), device="cuda")          # keeps the default stream busy for a while
+        for _ in range(20):
+            big = big * 1.0001 + 0.0
+        x = base + (big[0, :1, :1] * 0.0)                            # depends on the whole chain
+        flow = torch.empty(B, 2, H, Wd, device="cuda")
+        hard.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), unit_input=True)
+        hard.synchronize()
+        assert torch.equal(flow, flow_ref)
