@@ -55,7 +55,14 @@ struct Reader {
     FILE *f = nullptr;
     std::string err;
     std::map<int, Ref> seen;
+    std::vector<Ref> all;   // every object created: the nngraph node tables reference each other in cycles
     bool ok = true;
+
+    ~Reader()
+    {
+        // break the reference cycles, or the shared_ptr graph (~200 MB for a shipped model) is never freed
+        for (Ref &o : all) { o->items.clear(); o->payload.reset(); o->storage.reset(); }
+    }
 
     bool rd(void *p, size_t n)
     {
@@ -88,6 +95,7 @@ struct Reader {
     Ref object(int depth = 0)
     {
         Ref o = std::make_shared<Obj>();
+        all.push_back(o);
         if (!ok) return o;
         if (depth > 4000) { ok = false; err = "object nesting too deep"; return o; }
         const int tag = i32();
