@@ -64,8 +64,11 @@ def conv_layers(H, W):
     return out
 
 
-def conv_kernel_of(ci, co, stride, h, w):
-    """Kernel class a layer runs on -- the rule of b2f_api.hip (wino_mode, run_conv) with the default switches."""
+def conv_kernel_of(ci, co, stride, h, w, nimg=48):
+    """Kernel class a layer runs on -- the rule of b2f_api.hip (wino_mode, run_conv) with the default switches; nimg =
+    images of the launch (3 B for the siamese towers, B for a decoder).  The Winograd variant is chosen by block
+    rounds on 256 CUs: F(4x4) blocks 16 x 32 pixels x 64 outputs cost 60 each, F(2x2) blocks 8 x 16 x 64 cost 20 alone /
+    40 per co-resident pair, F(2x2) blocks of one 32-output N tile 13 / 26."""
     if ci == 3:
         return "conv_first"
     if stride == 1 and co == 2:
@@ -73,19 +76,26 @@ def conv_kernel_of(ci, co, stride, h, w):
     if stride == 1 and ci == 16 and co == 16:
         return "conv3x3_c16"
     if stride == 1 and co >= 32 and co % 4 == 0:
-        return "conv3x3_wino4" if h * w >= 4096 else "conv3x3_wino"
+        tiles2 = nimg * ((h + 7) // 8) * ((w + 15) // 16)
+        b4 = nimg * ((h + 15) // 16) * ((w + 31) // 32) * ((co + 63) // 64)
+        nblk2 = 1 if co <= 32 else (co + 63) // 64
+        b2, b2s = tiles2 * nblk2, tiles2 * ((co + 31) // 32)
+        t4 = 60 * ((b4 + 255) // 256)
+        t2 = 20 if b2 <= 256 else 40 * ((b2 + 511) // 512)
+        t2s = t2 if co <= 32 else (13 if b2s <= 256 else 26 * ((b2s + 511) // 512))
+        return "conv3x3_wino" if min(t2, t2s) < t4 else "conv3x3_wino4"
     if stride == 1 and co >= 16:
         return "conv3x3_wino"
     return "conv3x3_s%d" % stride
 
 
-def conv_flops_by_kernel(H, W):
-    """Per kernel class and triplet: (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes).  Executed:
+def conv_flops_by_kernel(H, W, B=16):
+    """Per kernel class and triplet (in a batch of B): (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes).  Executed:
     F(4x4) 36/16 MACs per output and channel pair, F(2x2) 16/4, direct 9; input channels padded to 8 (the decoder's
     first layer reads the 168-slot cost-volume record), outputs to 32 (16 for the 16 -> 16 kernel); VALU kernels 0."""
     alg, exe = {}, {}
     for ci, co, stride, h, w, calls in conv_layers(H, W):
-        k = conv_kernel_of(ci, co, stride, h, w)
+        k = conv_kernel_of(ci, co, stride, h, w, nimg=3 * B if calls == 3 else B)
         n = float(h * w * calls)
         cip = (ci + 7) // 8 * 8
         if ci >= 162:
@@ -295,7 +305,7 @@ def main():
             corr_ms /= args.steps
             corr_n /= args.steps
             tr = pmc_traffic(B, H, W)
-            alg_k, exe_k = conv_flops_by_kernel(H, W)
+            alg_k, exe_k = conv_flops_by_kernel(H, W, B)
             kms = {}
             for k, (ms, n) in prof.items():                      # profile rows -> kernel classes (rows carry an _ntN suffix)
                 for cls in alg_k:
