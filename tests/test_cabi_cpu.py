@@ -95,3 +95,31 @@ def test_header_is_plain_c99_and_the_library_links_from_c(tmp_path):
     exe = _build_c_example(tmp_path)
     r = subprocess.run([exe, "random:hard", "/nonexistent", "64", "64", str(tmp_path / "o")], capture_output=True)
     assert r.returncode == 3 and b"cannot read" in r.stderr
+
+
+def _prototypes(text):
+    """{name: normalized 'ret(args)'} of every b2f_* function declared in a C fragment."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = text.replace("B2F_API", " ")
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(b2f_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        norm = lambda t: re.sub(r"\s*\*\s*", "*", re.sub(r"\s+", " ", t)).strip()
+        args = [re.sub(r"\b\w+$", "", norm(a)).strip() if norm(a) != "void" else "void" for a in m.group(3).split(",")]
+        out[m.group(2)] = norm(m.group(1)) + "(" + ",".join(args) + ")"
+    return out
+
+
+def test_lua_shim_cdef_matches_the_header():
+    """lua/back2future.lua cannot be run here (no LuaJIT); at least its ffi.cdef block must declare the entry points
+    exactly as include/b2f.h does (return type and argument types, names aside)."""
+    lua = open(os.path.join(ROOT, "lua", "back2future.lua")).read()
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S).group(1)
+    hdr = _prototypes(open(os.path.join(ROOT, "include", "b2f.h")).read())
+    shim = _prototypes(cdef)
+    assert {"b2f_init", "b2f_compute_flow", "b2f_destroy", "b2f_last_error"} <= set(shim)
+    for name, proto in shim.items():
+        assert name in hdr, name
+        assert proto == hdr[name], (name, proto, hdr[name])
+    for name in re.findall(r"lib\.(b2f_\w+)", lua):
+        assert name in shim, "%s is called but not declared in the cdef block" % name
