@@ -105,7 +105,13 @@ def _prototypes(text):
     out = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(b2f_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         norm = lambda t: re.sub(r"\s*\*\s*", "*", re.sub(r"\s+", " ", t)).strip()
-        args = [re.sub(r"\b\w+$", "", norm(a)).strip() if norm(a) != "void" else "void" for a in m.group(3).split(",")]
+        def strip_name(a):            # drop the parameter name, if there is one
+            a = norm(a)
+            mm = re.match(r"^(.*?)(\b[A-Za-z_]\w*)$", a)
+            if mm and mm.group(1).strip() and mm.group(2) not in ("int", "float", "double", "char", "long", "void", "unsigned"):
+                return mm.group(1).strip()
+            return a
+        args = [strip_name(a) for a in m.group(3).split(",")]
         out[m.group(2)] = norm(m.group(1)) + "(" + ",".join(args) + ")"
     return out
 
@@ -123,3 +129,15 @@ def test_lua_shim_cdef_matches_the_header():
         assert proto == hdr[name], (name, proto, hdr[name])
     for name in re.findall(r"lib\.(b2f_\w+)", lua):
         assert name in shim, "%s is called but not declared in the cdef block" % name
+
+
+def test_integration_doc_prototypes_match_the_header():
+    """Every b2f_* prototype quoted in INTEGRATION.md is the header's."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    hdr = _prototypes(open(os.path.join(ROOT, "include", "b2f.h")).read())
+    quoted = {}
+    for block in re.findall(r"```[a-z]*\n(.*?)```", doc, flags=re.S):
+        quoted.update(_prototypes(block))
+    assert quoted, "no prototypes found in INTEGRATION.md"
+    for name, proto in quoted.items():
+        assert name in hdr and proto == hdr[name], (name, proto, hdr.get(name))
