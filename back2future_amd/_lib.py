@@ -40,6 +40,7 @@ SIGNATURES = {
     "b2f_output_shapes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.c_int]),
     "b2f_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "b2f_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "b2f_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                    C.c_int, C.POINTER(C.c_int)]),
     "b2f_profile_reset": (C.c_int, [C.c_void_p]),

@@ -38,6 +38,7 @@ class Model(object):
         _lib.check(L.b2f_init(name.encode() if name is not None else None, int(device), C.byref(h)))
         self._h = h
         self.name = name
+        self.device = int(device)
         lv, win, pf, no, npar = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
         _lib.check(L.b2f_info(h, C.byref(lv), C.byref(win), C.byref(pf), C.byref(no), C.byref(npar)))
         self.levels, self.win, self.past_flow = lv.value, win.value, bool(pf.value)
@@ -73,6 +74,27 @@ class Model(object):
 
     def set_option(self, key, value):
         _lib.check(_lib.lib().b2f_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        _lib.check(_lib.lib().b2f_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kv):
+        """Context manager: set options for the duration of a `with` block, then restore the previous values."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            old = {k: self.get_option(k) for k in kv}
+            try:
+                for k, v in kv.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return _cm()
 
     def synchronize(self):
         _lib.check(_lib.lib().b2f_synchronize(self._h))

@@ -211,7 +211,6 @@ int pack_all(b2f_ctx *c, const float *flat)
         c->wpk_floats = total;
     }
     HIPCHK(hipMemcpy(c->wpk_dev, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
-    // a packed layout change invalidates captured graphs only through pointers; they stay valid
     return 0;
 }
 
@@ -311,13 +310,12 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     // the chip idle.  An F(4x4) block (16 x 32 pixels, one per CU) takes about three times as long as an F(2x2)
     // block (8 x 16 pixels) that has its CU to itself and 1.5 times as long as one that shares it with a second
     // block, so compare the number of block rounds each kernel needs on 256 CUs.
-    // (B2F_WINO4_MIN_PIXELS=n: plain rule instead, F(2x2) below n pixels per map.)
-    const char *small_env = getenv("B2F_WINO4_MIN_PIXELS");   // read per call: tests switch it
-    const int small_px = small_env ? atoi(small_env) : -1;
+    // That rule makes a triplet's result depend (at 1e-6 level) on the batch it is computed in, so it is opt-in
+    // (option adaptive_kernels); the default rule looks at the map size only: F(2x2) below wino4_min_pixels.
     bool alt = false, split = false;
     if (p.wino == 4) {
-        if (small_px >= 0) {
-            alt = H * W < small_px;
+        if (!c->adaptive_kernels) {
+            alt = H * W < c->wino4_min_pixels;
         } else {
             // cost in twentieths of a lone F(2x2) block: F(4x4) block 60; F(2x2) block 20 alone, 40 per pair sharing a CU;
             // F(2x2) block that computes one of the two N tiles only 13 / 26
@@ -356,7 +354,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.nsplit = split ? 1 : 0;
     L.leaky = leaky;
     char name[48];
-    static const bool per_layer = getenv("B2F_PROFILE_LAYERS") != nullptr;   // one profile row per (layer shape, map size)
+    const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
         snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? "C16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
@@ -464,9 +462,11 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.out_chunk_stride = (long)(hw * 8);
         cl.out_pix_stride = 8;
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
+        cl.variant = c->corr_variant;
+        cl.ablate = c->corr_ablate;
         {
             char cname[48];
-            snprintf(cname, sizeof cname, getenv("B2F_PROFILE_LAYERS") ? "warp_costvol_%dx%d" : "warp_costvol", h, w);
+            snprintf(cname, sizeof cname, c->profile_layers ? "warp_costvol_%dx%d" : "warp_costvol", h, w);
             Scope sc(c, s, cname, cap);
             HIPCHK(launch_warp_costvol(cl, s));
         }
@@ -558,6 +558,9 @@ bool ends_with(const std::string &s, const char *suf)
 int install_weights(b2f_ctx *c, const float *flat, long long n, bool past)
 {
     if (n != param_count(past)) return fail("b2f: weight count does not match the architecture");
+    // captured graphs hold the packed-weight pointers and the Hard / Soft topology of the moment they were captured
+    HIPCHK(hipDeviceSynchronize());
+    drop_graphs(c);
     if (c->w_dev && (c->nparams != n)) { HIPCHK(hipFree(c->w_dev)); c->w_dev = nullptr; }
     c->past_flow = past;
     c->nparams = n;
@@ -647,6 +650,18 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
     }
     b2f_ctx *c = new b2f_ctx();
     c->device = device;
+    {   // defaults of the tuning options may come from the environment; read here once, never on the hot path
+        auto env_int = [](const char *k, long long dflt) { const char *v = getenv(k); return v ? atoll(v) : dflt; };
+        c->wino4_min_pixels = (int)env_int("B2F_WINO4_MIN_PIXELS", c->wino4_min_pixels);
+        c->adaptive_kernels = (int)env_int("B2F_ADAPTIVE_KERNELS", c->adaptive_kernels);
+        c->corr_variant = (int)env_int("B2F_CORR_LAT", c->corr_variant);
+        c->corr_ablate = (int)env_int("B2F_CORR_ABLATE", c->corr_ablate);
+        c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
+        c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
+        c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
+        c->host_u8 = (int)env_int("B2F_HOST_U8", c->host_u8);
+        c->host_ramp = (int)env_int("B2F_HOST_RAMP", c->host_ramp);
+    }
     // a blocking stream: ordered with the legacy default stream like any such stream, so inputs that PyTorch (whose
     // default stream is the null stream) or hipMemcpy / hipMemset produced there are complete before our kernels read them
     if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
@@ -733,6 +748,7 @@ int b2f_commit_weights(b2f_ctx *c) try
     if (!c) return fail("b2f_commit_weights: null context");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
+    drop_graphs(c);   // pack_all may move wpk_dev
     std::vector<float> flat((size_t)c->nparams);
     HIPCHK(hipMemcpy(flat.data(), c->w_dev, flat.size() * sizeof(float), hipMemcpyDeviceToHost));
     return pack_all(c, flat.data());
@@ -745,10 +761,49 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     if (!strcmp(key, "use_graph")) c->use_graph = value;
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
+    else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
+    else if (!strcmp(key, "wino4_min_pixels") || !strcmp(key, "adaptive_kernels")) {
+        // a different kernel mix: captured graphs hold the old one
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        (key[0] == 'w' ? c->wino4_min_pixels : c->adaptive_kernels) = value;
+    } else if (!strcmp(key, "corr_variant") || !strcmp(key, "corr_ablate")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        (key[5] == 'v' ? c->corr_variant : c->corr_ablate) = value;
+    } else if (!strcmp(key, "op_wino_split")) c->op_wino_split = value;
+    else if (!strcmp(key, "host_subbatch_pixels")) c->host_subbatch_pixels = value > 0 ? value : (16ll << 20);
+    else if (!strcmp(key, "host_threads")) c->host_threads = value;
+    else if (!strcmp(key, "host_u8")) c->host_u8 = value;
+    else if (!strcmp(key, "host_ramp")) c->host_ramp = value;
     else return fail(std::string("b2f_set_option: unknown key ") + key);
     return 0;
 }
 B2F_CATCH("b2f_set_option")
+
+int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
+{
+    if (!c || !key || !value) return fail("b2f_get_option: null argument");
+    const std::string k(key);
+    if (k == "use_graph") *value = c->use_graph;
+    else if (k == "host_graph") *value = c->host_graph;
+    else if (k == "profile") *value = c->profile;
+    else if (k == "profile_layers") *value = c->profile_layers;
+    else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
+    else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
+    else if (k == "corr_variant") *value = c->corr_variant;
+    else if (k == "corr_ablate") *value = c->corr_ablate;
+    else if (k == "op_wino_split") *value = c->op_wino_split;
+    else if (k == "host_subbatch_pixels") *value = (int)std::min<long long>(c->host_subbatch_pixels, 0x7fffffff);
+    else if (k == "host_threads") *value = c->host_threads;
+    else if (k == "host_u8") *value = c->host_u8;
+    else if (k == "host_ramp") *value = c->host_ramp;
+    else return fail("b2f_get_option: unknown key " + k);
+    return 0;
+}
+B2F_CATCH("b2f_get_option")
 
 int b2f_synchronize(b2f_ctx *c) try
 {
@@ -800,7 +855,10 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
     Outs O;
     O.flow = dev_flow; O.occ = dev_occ; O.est3 = dev_est3;
     if (graph && !c->profile) {
-        if (c->graphs.size() > 256) drop_graphs(c);   // callers that keep changing pointers: start over
+        if (c->graphs.size() > 256) {   // callers that keep changing pointers: start over (replays may still be in flight)
+            HIPCHK(hipDeviceSynchronize());
+            drop_graphs(c);
+        }
         const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -991,6 +1049,7 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     cl.k = k; cl.out = dcv.p;
     cl.out_img_stride = (long)(hw * kCvRec); cl.out_chunk_stride = 8; cl.out_pix_stride = kCvRec;
     cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
+    cl.variant = c->corr_variant;
     HIPCHK(launch_warp_costvol(cl, c->stream));
     std::vector<float> rec((size_t)B * hw * kCvRec);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1051,8 +1110,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int nt, nblk;
     int wino = (stride == 1 && use_wino() && Ci == 16 && Co == 16) ? 3 : stride == 1 ? wino_mode(Co) : 0;
-    // tests: B2F_OP_WINO_SPLIT=1 runs F(4x4)-eligible layers on the F(2x2) kernel, one block per 32-output N tile
-    const bool op_split = getenv("B2F_OP_WINO_SPLIT") && wino == 4 && Co > 32;
+    // tests: option op_wino_split = 1 runs F(4x4)-eligible layers on the F(2x2) kernel, one block per 32-output N tile
+    const bool op_split = c->op_wino_split && wino == 4 && Co > 32;
     if (op_split) wino = 2;
     if (wino == 4) { nt = 2; nblk = wino4_nblk(Co); }
     else if (wino == 1 || wino == 3) { nt = 1; nblk = 1; }

@@ -308,16 +308,13 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     if (p_in.C % 8 != 0 || p_in.pix_stride % 4 != 0 || p_in.chunk_stride % 4 != 0 || p_in.out_pix_stride % 4 != 0 ||
         p_in.out_chunk_stride % 4 != 0)
         return hipErrorInvalidValue;
-    static const int ablate = getenv("B2F_CORR_ABLATE") ? atoi(getenv("B2F_CORR_ABLATE")) : 0;
     CorrLaunch p = p_in;
-    p.ablate = ablate;
+    const int ablate = p.ablate;
     const bool pow2 = (p.C & (p.C - 1)) == 0;
     const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
     dim3 grid((unsigned)(tiles_x * tiles_y * p.B));
-    // at most one round of two blocks per CU: the latency variant (B2F_CORR_LAT=0|1 forces either)
-    const char *lat_s = getenv("B2F_CORR_LAT");   // read per call: tests switch it
-    const int lat_env = lat_s ? atoi(lat_s) : -1;
-    const bool lat = lat_env >= 0 ? lat_env != 0 : grid.x <= 512 && !ablate;
+    // at most one round of two blocks per CU: the latency variant (p.variant = 0 | 1 forces either)
+    const bool lat = p.variant >= 0 ? p.variant != 0 : grid.x <= 512 && !ablate;
     if (lat) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_kernel<true, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_kernel<false, true>), grid, dim3(256), 0, s, p);

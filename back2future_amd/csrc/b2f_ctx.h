@@ -213,6 +213,19 @@ struct b2f_ctx {
     // options
     int use_graph = 0, profile = 0;
     int host_graph = 1;   // b2f_compute_flow*: replay hipGraphs for repeated (shape, sub-batch) combinations
+    // kernel selection and pipeline tuning (b2f_set_option; seeded once from the environment in b2f_init, never read
+    // from it on the hot path)
+    int wino4_min_pixels = 4096;   // F(4x4) for maps of at least this many pixels, F(2x2) below: depends on the map size
+                                   // only, so a triplet's result does not depend on the batch it is computed in
+    int adaptive_kernels = 0;      // 1: choose the Winograd variant per launch by block rounds on the 256 CUs (faster for
+                                   // single triplets / small batches; results then depend on the batch size at 1e-6 level)
+    int corr_ablate = 0;           // profiling only, see CorrLaunch::ablate
+    int corr_variant = -1;         // warp + cost volume: -1 auto, 0 regular, 1 latency variant (bit-identical results)
+    int op_wino_split = 0;         // b2f_op_conv3x3: F(2x2) kernel with one block per 32-output N tile (tests)
+    int profile_layers = 0;        // one profile row per (layer shape, map size)
+    long long host_subbatch_pixels = 16ll << 20;
+    int host_threads = 0;          // 0 = auto
+    int host_u8 = 1, host_ramp = 1;
     std::map<b2f::GraphKey, hipGraphExec_t> graphs;
     // profiling
     std::vector<std::string> prof_names;

@@ -99,7 +99,8 @@ struct CorrLaunch {
     long out_img_stride, out_chunk_stride;
     int out_pix_stride;
     int B, C, h, w;
-    int ablate;                              // profiling only (env B2F_CORR_ABLATE): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
+    int ablate = 0;                          // profiling only (option corr_ablate): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
+    int variant = -1;                        // -1 auto, 0 regular, 1 latency instantiation (same arithmetic, same bits)
 };
 #ifdef __HIPCC__
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one

@@ -93,7 +93,7 @@ int ensure_slot(b2f_ctx *c, HostSlot &hs, int SB, size_t hw0, size_t hw, int H0,
 // The link is the bound of this entry point (one MI355X box: 56 GB/s in either direction, but only 55 GB/s for
 // both together), so both directions carry as few bytes as exactness allows: inputs that are k / 255 go up as
 // bytes (pack_u8_piece), the flow comes down as the network's fp32 values and becomes `double * sc` on the host
-// (back2future.lua:80-84), exactly the reference's arithmetic.  Host threads (B2F_HOST_THREADS, default 16, two
+// (back2future.lua:80-84), exactly the reference's arithmetic.  Host threads (option host_threads, default 16, two
 // thirds on the input side; the output side is driven by a second control thread) do the packing / staging and
 // the f32 -> f64 conversion; page-locked caller buffers are DMA'd in place where no conversion is involved.
 namespace {
@@ -110,15 +110,14 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
     const bool same = (fw == W0 && fh == H0);
     const int C3 = c->past_flow ? 2 : 3;
     const double sc_h = (double)H0 / (double)fh, sc_w = (double)W0 / (double)fw;   // :78-79
-    const long long sub_px = getenv("B2F_HOST_SUBBATCH_PIXELS") ? atoll(getenv("B2F_HOST_SUBBATCH_PIXELS")) : (16ll << 20);
-    const int nthreads = std::max(2, getenv("B2F_HOST_THREADS") ? atoi(getenv("B2F_HOST_THREADS"))
-                                                                 : (int)std::min(16u, std::thread::hardware_concurrency()));
-    const bool use_u8 = bytes_in || !(getenv("B2F_HOST_U8") && atoi(getenv("B2F_HOST_U8")) == 0);
+    const long long sub_px = c->host_subbatch_pixels;
+    const int nthreads = std::max(2, c->host_threads > 0 ? c->host_threads : (int)std::min(16u, std::thread::hardware_concurrency()));
+    const bool use_u8 = bytes_in || c->host_u8 != 0;
     const size_t esz = bytes_in ? 1 : 4;   // bytes per input sample in the caller's buffers
     const int SB = (int)std::min<long long>(n, std::max<long long>(1, sub_px / (long long)hw0));
     // sub-batch sizes ramp up from ~2 Mpx (one full-HD triplet) by doubling to SB: the kernels start after a small
-    // upload instead of SB triplets' (B2F_HOST_RAMP=0: uniform sizes)
-    const bool ramp = !(getenv("B2F_HOST_RAMP") && atoi(getenv("B2F_HOST_RAMP")) == 0);
+    // upload instead of SB triplets' (option host_ramp = 0: uniform sizes)
+    const bool ramp = c->host_ramp != 0;
     const int sz0 = ramp ? (int)std::min<long long>(SB, std::max<long long>(1, (2ll << 20) / (long long)hw0)) : SB;
     std::vector<std::pair<size_t, int>> subs;   // (first triplet, count)
     for (int b0 = 0, sz = sz0; b0 < n; sz = std::min(2 * sz, SB)) {

@@ -30,7 +30,10 @@ def broadcast_weights(model, src=0):
     import torch
     import torch.distributed as dist
     ptr, n = model.weights_device_ptr()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", model.device)      # the GPU the context was created on, not torch's current one
+    assert torch.cuda.current_device() == model.device, \
+        "broadcast_weights: torch's current device (%d) is not the context's (%d); call torch.cuda.set_device first" \
+        % (torch.cuda.current_device(), model.device)
     # wrap the library's device buffer without copying: broadcast straight into it
     class _Ext(object):
         pass
@@ -38,9 +41,17 @@ def broadcast_weights(model, src=0):
     holder.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
     flat = torch.as_tensor(holder, device=dev)
     dist.broadcast(flat, src=src)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     model.commit_weights()
     return n
+
+
+def weights_checksum(model):
+    """64-bit checksum of the context's flat weight buffer as it sits on the device (after a broadcast every rank
+    must report the same value)."""
+    import zlib
+    w = model.get_weights()
+    return (zlib.crc32(w.tobytes()) << 32) | zlib.adler32(w.tobytes())
 
 
 def gather_host(local, counts=None):

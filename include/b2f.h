@@ -130,8 +130,18 @@ B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh
 /* Execution options: use_graph (default 0) = b2f_forward_device replays a hipGraph per
  * (shape, pointers) combination, captured on its second use; host_graph (default 1) = the
  * same inside b2f_compute_flow*; profile = record HIP events around every kernel launch
- * (eager mode).                                                                       */
+ * (eager mode); profile_layers = one profile row per layer shape.
+ * Kernel selection: wino4_min_pixels (default 4096) = stride-1 convs run the Winograd F(4x4)
+ * kernel on maps of at least that many pixels and F(2x2) below -- a rule of the map size only,
+ * so a triplet's result never depends on the batch it is computed in; adaptive_kernels = 1
+ * picks the variant per launch by block rounds on the 256 CUs instead (faster for single
+ * triplets, results then vary at the 1e-6 level with the batch size); corr_variant (-1 auto /
+ * 0 / 1) forces an instantiation of the warp + cost-volume kernel (same bits either way).
+ * Host pipeline of b2f_compute_flow*: host_subbatch_pixels, host_threads (0 = auto), host_u8,
+ * host_ramp.  The library reads no environment variable after b2f_init (which takes
+ * B2F_<OPTION> as the initial value of the tuning options).                              */
 B2F_API int b2f_set_option(b2f_ctx *ctx, const char *key, int value);
+B2F_API int b2f_get_option(const b2f_ctx *ctx, const char *key, int *value);
 /* Per-kernel-class timings gathered while profile=1.  names: cap x 32 chars.        */
 B2F_API int b2f_profile_read(b2f_ctx *ctx, char *names, double *total_ms, long long *launches,
                      int cap, int *n);

@@ -377,18 +377,48 @@ ORC_API void orc_warping_unit(const float *I, const float *F, float k, int B, in
 }
 
 /* ------------------------------------------------------------------------- */
-/* The shipped architecture: createModelMulti(opt) of models/pwc.lua:87-508 with
- * opts.lua:83-98 (frames 3, levels 7, residual 0, occ_input 0, rescale_flow 0,
- * flownet_factor 20, pwc_ws 9, pwc_skip 2, pwc_siamese 1, pwc_sum_cvs false,
- * two_frame 0), past_flow = false ("Ours-Hard") / true ("Ours-Soft-*").
+/* createModelMulti(opt) of models/pwc.lua:87-508, every branch the option table
+ * selects (frames = 3, pwc_siamese = 1 and pwc_skip >= 1 are fixed: the only values
+ * the reference's CostVolMulti call sites / shipped models use).
+ * The shipped models are opts.lua:83-98: levels 7, pwc_ws 9, pwc_skip 2, residual 0,
+ * occ_input 0, rescale_flow 0, flownet_factor 20, pwc_sum_cvs false, two_frame 0,
+ * past_flow = false ("Ours-Hard") / true ("Ours-Soft-*"); createModelMulti(nil)
+ * defaults to win 5 / levels 4 (pwc.lua:88).
  *
  * Canonical flat weight order used by this repo (oracle and product agree on
- * it): feature units l = 2..7 {conv1.w, conv1.b, conv2.w,
- * conv2.b}; then for l = 7..3: occ decoder, flow decoder, [past-flow decoder],
- * each 6 x {w, b}; every w in Torch layout Co x Ci x 3 x 3.                   */
-enum { LEVELS = 7, L_ST = 3, WIN = 9 };
+ * it) = graph-construction order of pwc.lua: feature units
+ * l = 2..levels {conv1.w, conv1.b, conv2.w, conv2.b}; then for l = levels..l_st:
+ * occ decoder, flow decoder, [past-flow decoder], each 6 x {w, b}; every w in
+ * Torch layout Co x Ci x 3 x 3.                                               */
+typedef struct orc_opts {
+    int win;            /* opt.pwc_ws        pwc.lua:88,108  */
+    int levels;         /* opt.levels        :88,110         */
+    int skip;           /* opt.pwc_skip      :93,114  (l_st = skip + 1, :136) */
+    int two_frame;      /* opt.two_frame     :91,116         */
+    int sum_cvs;        /* opt.pwc_sum_cvs   :92,119         */
+    int residual;       /* opt.residual      :97,113         */
+    int occ_input;      /* opt.occ_input     :98,111         */
+    int rescale_flow;   /* opt.rescale_flow  :95,118         */
+    int past_flow;      /* opt.past_flow     :101,120        */
+    float flownet_factor; /* opt.flownet_factor :94,117      */
+    int pruned;         /* not a reference option: 1 = compute only what computeFlow reads (est[1], est[3],
+                           back2future.lua:77,87); the other output-table entries are left untouched */
+} orc_opts;
+
 static const int FEAT[8] = {0, 3, 16, 32, 64, 96, 128, 192}; /* featMaps, pwc.lua:29,89 */
 static const int DEC[7] = {0, 128, 128, 96, 64, 32, 2};       /* decoder(), pwc.lua:76-85 */
+
+ORC_API void orc_default_opts(orc_opts *o, int past_flow)
+{
+    o->win = 9; o->levels = 7; o->skip = 2; o->two_frame = 0; o->sum_cvs = 0; o->residual = 0;
+    o->occ_input = 0; o->rescale_flow = 0; o->past_flow = past_flow ? 1 : 0; o->flownet_factor = 20.f;
+    o->pruned = 0;
+}
+
+static int opts_ok(const orc_opts *o)
+{
+    return o->win >= 1 && (o->win & 1) && o->levels >= 2 && o->levels <= 7 && o->skip >= 1 && o->skip + 1 <= o->levels;
+}
 
 static long conv_params(int ci, int co) { return (long)co * ci * 9 + co; }
 static long decoder_params(int n)
@@ -398,18 +428,37 @@ static long decoder_params(int n)
     for (int i = 1; i <= 6; ++i) { s += conv_params(ci, DEC[i]); ci = DEC[i]; }
     return s;
 }
-static int occ_in_ch(int l) { return 2 * WIN * WIN + FEAT[l] + (l != LEVELS ? 2 : 0); }   /* pwc.lua:288-304 */
-static int flow_in_ch(int l) { return l == LEVELS ? 2 * WIN * WIN : 2 * WIN * WIN + FEAT[l] + 2; } /* :325-337 */
+/* pwc.lua:254-285: channels of the cost volume the flow / occlusion decoders see */
+static int nd_flow(const orc_opts *o) { return (o->two_frame || o->sum_cvs) ? o->win * o->win : 2 * o->win * o->win; }
+static int nd_occ(const orc_opts *o) { return o->two_frame ? o->win * o->win : 2 * o->win * o->win; }
+/* pwc.lua:288-305 */
+static int occ_in_ch(const orc_opts *o, int l)
+{
+    int n = nd_occ(o) + FEAT[l];
+    if (o->two_frame) n += FEAT[l];
+    if (l != o->levels) { n += 2; if (o->occ_input) n += 2; }
+    return n;
+}
+/* pwc.lua:325-337 */
+static int flow_in_ch(const orc_opts *o, int l) { return l == o->levels ? nd_flow(o) : nd_flow(o) + FEAT[l] + 2; }
+
+ORC_API long orc_param_count_ex(const orc_opts *o)
+{
+    if (!opts_ok(o)) return -1;
+    long s = 0;
+    for (int l = 2; l <= o->levels; ++l) s += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
+    for (int l = o->levels; l >= o->skip + 1; --l) {
+        s += decoder_params(occ_in_ch(o, l)) + decoder_params(flow_in_ch(o, l));
+        if (o->past_flow) s += decoder_params(flow_in_ch(o, l));
+    }
+    return s;
+}
 
 ORC_API long orc_param_count(int past_flow)
 {
-    long s = 0;
-    for (int l = 2; l <= LEVELS; ++l) s += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
-    for (int l = LEVELS; l >= L_ST; --l) {
-        s += decoder_params(occ_in_ch(l)) + decoder_params(flow_in_ch(l));
-        if (past_flow) s += decoder_params(flow_in_ch(l));
-    }
-    return s;
+    orc_opts o;
+    orc_default_opts(&o, past_flow);
+    return orc_param_count_ex(&o);
 }
 
 static float *falloc(long n) { return (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); }
@@ -424,9 +473,11 @@ static const float *conv_unit(const float *x, int B, int ci, int co, int H, int 
     return b2 + co;
 }
 
-/* decoder(n) -- pwc.lua:76-85: six 3x3 convs, LeakyReLU(0.2) after the first five */
+/* decoder(n) -- pwc.lua:76-85: six 3x3 convs, LeakyReLU(0.2) after the first five.
+ * y == NULL: skip the computation (pruned mode), only advance the parameter pointer. */
 static const float *run_decoder(const float *x, int B, int n, int h, int w, const float *p, float *y)
 {
+    if (!y) return p + decoder_params(n);
     const long hw = (long)h * w;
     float *a = falloc((long)B * 128 * hw), *b = falloc((long)B * 128 * hw);
     const float *in = x;
@@ -457,21 +508,40 @@ static void join_channels(float *dst, int B, long hw, int nsrc, const float *con
     }
 }
 
-/* model:forward(imgs) for the shipped graph.  x: B x 9 x H x W (normalized),
- * H, W multiples of 64.  outs: n_outputs tensors in the order of the output
- * table, pwc.lua:459-489 (finest level first: skip_ufs[l], [skip_ubfs[l]],
- * skip_occs[l], iws[1][l], iws[3][l] for l = 3..7); caller allocates:
- * flow/occ tensors B x 2 x 4h_l x 4w_l, warped images B x 3 x 4h_l x 4w_l.
- * Returns the number of output tensors (20 Hard / 25 Soft).                  */
-ORC_API int orc_pwc_forward(const float *x, int B, int H, int W, const float *params,
-                            int past_flow, float **outs)
+/* Output table of model:forward, pwc.lua:459-489 with skip > 0: per level l = l_st..levels
+ * skip_ufs[l], [skip_ubfs[l]], skip_occs[l], iws[1][l], iws[3][l], all at (H, W) >> (l - l_st).  */
+ORC_API int orc_pwc_output_shapes_ex(int H, int W, const orc_opts *o, int *ch, int *oh, int *ow)
 {
-    const int frames = 3, ref = 2;
-    float *Is[4] = {0}, *ds[4][6] = {{0}}, *cs[4][8] = {{0}}, *ws[4][8] = {{0}};
-    float *fs[8] = {0}, *bfs[8] = {0}, *ufs[8] = {0}, *ubfs[8] = {0};
-    float *skip_ufs[8] = {0}, *skip_ubfs[8] = {0}, *occs[8] = {0}, *skip_occs[8] = {0};
-    float *iws[4][8] = {{0}};
-    int hh[8], wl[8];
+    int no = 0;
+    const int l_st = o->skip + 1;
+    for (int l = l_st; l <= o->levels; ++l) {
+        const int per = o->past_flow ? 5 : 4;
+        for (int j = 0; j < per; ++j) {
+            const int is_img = (j >= per - 2);
+            ch[no] = is_img ? 3 : 2; oh[no] = H >> (l - l_st); ow[no] = W >> (l - l_st); ++no;
+        }
+    }
+    return no;
+}
+
+/* model:forward(imgs).  x: B x 9 x H x W (normalized), H, W multiples of 2^(levels-1).
+ * outs: the output table in order (see orc_pwc_output_shapes_ex); caller allocates.  In
+ * pruned mode only skip_ufs[l_st], skip_occs[l_st] and -- without past_flow -- iws[1][l_st]
+ * (computeFlow's est[1] / est[3], back2future.lua:77,87) are written.
+ * Returns the number of output tensors, -1 for unsupported options.                    */
+ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float *params,
+                               const orc_opts *o, float **outs)
+{
+    if (!opts_ok(o) || (H % (1 << (o->levels - 1))) || (W % (1 << (o->levels - 1)))) return -1;
+    const int frames = 3, ref = 2; /* :130-133 */
+    const int LEVELS = o->levels, L_ST = o->skip + 1 /* :136 */, WIN = o->win, nd = WIN * WIN;
+    const int f_i = o->two_frame ? ref : 1, l_i = o->two_frame ? ref + 1 : frames; /* :160-165 */
+    const int pruned = o->pruned;
+    float *Is[4] = {0}, *ds[4][8] = {{0}}, *cs[4][8] = {{0}}, *ws[4][8] = {{0}};
+    float *fs[9] = {0}, *bfs[9] = {0}, *ufs[9] = {0}, *ubfs[9] = {0}, *uoccs[9] = {0};
+    float *skip_ufs[9] = {0}, *skip_ubfs[9] = {0}, *occs[9] = {0}, *skip_occs[9] = {0};
+    float *iws[4][9] = {{0}};
+    int hh[9], wl[9];
     for (int l = 1; l <= LEVELS; ++l) { hh[l] = H >> (l - 1); wl[l] = W >> (l - 1); }
     const long HW = (long)H * W;
 
@@ -485,146 +555,202 @@ ORC_API int orc_pwc_forward(const float *x, int B, int H, int W, const float *pa
     for (int f = 1; f <= frames; ++f) {
         if (f == ref) continue;
         ds[f][1] = Is[f];
+        if (pruned) continue;
         for (int k = 2; k <= LEVELS - L_ST + 1; ++k) {
             ds[f][k] = falloc((long)B * 3 * (H >> (k - 1)) * (W >> (k - 1)));
             orc_avgpool2(ds[f][k - 1], B * 3, H >> (k - 2), W >> (k - 2), ds[f][k]);
         }
     }
-    /* siamese feature pyramid, shared weights -- pwc.lua:169-211 */
-    const float *p = params, *pdec;
+    /* siamese feature pyramid, shared weights -- pwc.lua:169-211; frames f_i..l_i only */
+    const float *p = params;
     {
         const float *pn = p;
-        for (int f = 1; f <= frames; ++f) {
+        for (int l = 2; l <= LEVELS; ++l) pn += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
+        for (int f = f_i; f <= l_i; ++f) {
             cs[f][1] = Is[f];
-            pn = p;
+            const float *q = p;
             for (int l = 2; l <= LEVELS; ++l) {
                 float *tmp = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
                 cs[f][l] = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
-                pn = conv_unit(cs[f][l - 1], B, FEAT[l - 1], FEAT[l], hh[l - 1], wl[l - 1], pn, tmp, cs[f][l]);
+                q = conv_unit(cs[f][l - 1], B, FEAT[l - 1], FEAT[l], hh[l - 1], wl[l - 1], q, tmp, cs[f][l]);
                 free(tmp);
             }
         }
-        pdec = pn;
+        p = pn;
     }
-    p = pdec;
 
     for (int l = LEVELS; l >= L_ST; --l) { /* pwc.lua:237 */
         const int h = hh[l], w = wl[l], C = FEAT[l];
         const long hw = (long)h * w;
-        float **input_f3 = (l == LEVELS) ? &cs[3][l] : &ws[3][l]; /* :238-244 */
-        float **input_f1 = (l == LEVELS) ? &cs[1][l] : &ws[1][l];
-        /* cost volumes -- :246-263 */
-        float *cv_fwd = falloc((long)B * 81 * hw), *cv_bwd = falloc((long)B * 81 * hw);
-        { const float *fr[2] = {cs[ref][l], *input_f3}; orc_costvol(fr, 2, B, C, h, w, WIN, 1, cv_fwd); }
-        { const float *fr[2] = {cs[ref][l], *input_f1}; orc_costvol(fr, 2, B, C, h, w, WIN, 0, cv_bwd); }
-        float *cv = falloc((long)B * 162 * hw); /* JoinTable :267 */
-        { const float *s[2] = {cv_fwd, cv_bwd}; int c[2] = {81, 81}; join_channels(cv, B, hw, 2, s, c); }
-        free(cv_fwd); free(cv_bwd);
-
-        /* occlusion decoder + SpatialSoftMax -- :288-308 */
-        {
-            const int n = occ_in_ch(l);
-            float *din = falloc((long)B * n * hw), *dout = falloc((long)B * 2 * hw);
-            const float *s[3] = {cv, cs[ref][l], (l != LEVELS) ? ufs[l + 1] : 0};
-            int c[3] = {162, C, 2};
-            join_channels(din, B, hw, (l != LEVELS) ? 3 : 2, s, c);
-            p = run_decoder(din, B, n, h, w, p, dout);
-            occs[l] = falloc((long)B * 2 * hw);
-            orc_spatial_softmax(dout, B, 2, h, w, occs[l]);
-            free(din); free(dout);
-            /* uoccs = nearest x2; skip_occs = one more nearest x2 (l_st-1 = 2) -- :311-321 */
-            float *uo = falloc((long)B * 2 * hw * 4);
-            orc_upsample_nearest2x(occs[l], B * 2, h, w, uo);
-            skip_occs[l] = falloc((long)B * 2 * hw * 16);
-            orc_upsample_nearest2x(uo, B * 2, 2 * h, 2 * w, skip_occs[l]);
-            free(uo);
+        /* :238-244: raw features on the coarsest level, warped ones below */
+        const float *in_fut = (l == LEVELS) ? cs[3][l] : ws[3][l];
+        const float *in_past = (l == LEVELS) ? cs[1][l] : ws[1][l];
+        /* cost volumes -- :246-285 */
+        float *cv_fwd = falloc((long)B * nd * hw), *cv_bwd = 0, *cv_join = 0, *cv_sum = 0;
+        { const float *fr[2] = {cs[ref][l], in_fut}; orc_costvol(fr, 2, B, C, h, w, WIN, 1, cv_fwd); }
+        const float *cvs_flow, *cvs_occ;
+        if (!o->two_frame) {
+            cv_bwd = falloc((long)B * nd * hw);
+            { const float *fr[2] = {cs[ref][l], in_past}; orc_costvol(fr, 2, B, C, h, w, WIN, 0, cv_bwd); }
+            cv_join = falloc((long)B * 2 * nd * hw); /* JoinTable :267 / :273 */
+            { const float *s[2] = {cv_fwd, cv_bwd}; int c[2] = {nd, nd}; join_channels(cv_join, B, hw, 2, s, c); }
+            if (!o->sum_cvs) {
+                cvs_flow = cv_join; cvs_occ = cv_join;
+            } else { /* CAddTable :272 */
+                cv_sum = falloc((long)B * nd * hw);
+                for (long i = 0; i < (long)B * nd * hw; ++i) cv_sum[i] = cv_fwd[i] + cv_bwd[i];
+                cvs_flow = cv_sum; cvs_occ = cv_join;
+            }
+        } else { /* :279-284 */
+            cvs_flow = cv_fwd; cvs_occ = cv_fwd;
         }
-        /* flow decoders -- :325-352 (residual = 0) */
+
+        /* occlusion decoder + SpatialSoftMax -- :288-322 */
         {
-            const int n = flow_in_ch(l);
+            const int n = occ_in_ch(o, l);
+            /* pruned: an occlusion map is live only at l_st, or everywhere when it feeds the next level (occ_input) */
+            const int live = !pruned || l == L_ST || o->occ_input;
+            if (live) {
+                float *din = falloc((long)B * n * hw), *dout = falloc((long)B * 2 * hw);
+                const float *s[5]; int c[5]; int ns = 0;
+                s[ns] = cvs_occ; c[ns++] = nd_occ(o);
+                s[ns] = cs[ref][l]; c[ns++] = C;
+                if (o->two_frame) { s[ns] = cs[ref + 1][l]; c[ns++] = C; }       /* :292-296 */
+                if (l != LEVELS) {
+                    s[ns] = ufs[l + 1]; c[ns++] = 2;                              /* :299-301 */
+                    if (o->occ_input) { s[ns] = uoccs[l + 1]; c[ns++] = 2; }      /* :302-305 */
+                }
+                join_channels(din, B, hw, ns, s, c);
+                p = run_decoder(din, B, n, h, w, p, dout);
+                occs[l] = falloc((long)B * 2 * hw);
+                orc_spatial_softmax(dout, B, 2, h, w, occs[l]);
+                free(din); free(dout);
+                /* uoccs = nearest x2 (:311-313); skip_occs = l_st - 2 more nearest x2 (:316-321) */
+                uoccs[l] = falloc((long)B * 2 * hw * 4);
+                orc_upsample_nearest2x(occs[l], B * 2, h, w, uoccs[l]);
+                float *cur = uoccs[l];
+                int ch_ = 2 * h, cw_ = 2 * w;
+                for (int i = 2; i <= L_ST - 1; ++i) {
+                    float *nx = falloc((long)B * 2 * ch_ * cw_ * 4);
+                    orc_upsample_nearest2x(cur, B * 2, ch_, cw_, nx);
+                    if (cur != uoccs[l]) free(cur);
+                    cur = nx; ch_ *= 2; cw_ *= 2;
+                }
+                skip_occs[l] = cur;
+            } else {
+                p = run_decoder(0, B, n, h, w, p, 0);
+            }
+        }
+        /* flow decoders -- :325-352 */
+        {
+            const int n = flow_in_ch(o, l);
+            const int past_live = o->past_flow && !pruned;
             fs[l] = falloc((long)B * 2 * hw);
+            if (past_live) bfs[l] = falloc((long)B * 2 * hw);
             if (l == LEVELS) {
-                p = run_decoder(cv, B, n, h, w, p, fs[l]);
-                if (past_flow) { bfs[l] = falloc((long)B * 2 * hw); p = run_decoder(cv, B, n, h, w, p, bfs[l]); }
+                p = run_decoder(cvs_flow, B, n, h, w, p, fs[l]);
+                if (o->past_flow) p = run_decoder(cvs_flow, B, n, h, w, p, past_live ? bfs[l] : 0);
             } else {
                 float *din = falloc((long)B * n * hw);
-                const float *s[3] = {cv, cs[ref][l], ufs[l + 1]};
-                int c[3] = {162, C, 2};
+                const float *s[3] = {cvs_flow, cs[ref][l], ufs[l + 1]};
+                int c[3] = {nd_flow(o), C, 2};
                 join_channels(din, B, hw, 3, s, c);
                 p = run_decoder(din, B, n, h, w, p, fs[l]);
-                if (past_flow) {
-                    s[2] = ubfs[l + 1];
-                    join_channels(din, B, hw, 3, s, c);
-                    bfs[l] = falloc((long)B * 2 * hw);
-                    p = run_decoder(din, B, n, h, w, p, bfs[l]);
+                if (o->residual) /* CAddTable :342 */
+                    for (long i = 0; i < (long)B * 2 * hw; ++i) fs[l][i] = fs[l][i] + ufs[l + 1][i];
+                if (o->past_flow) {
+                    if (past_live) { s[2] = ubfs[l + 1]; join_channels(din, B, hw, 3, s, c); }
+                    p = run_decoder(din, B, n, h, w, p, past_live ? bfs[l] : 0);
+                    if (past_live && o->residual) /* :344 */
+                        for (long i = 0; i < (long)B * 2 * hw; ++i) bfs[l][i] = bfs[l][i] + ubfs[l + 1][i];
                 }
                 free(din);
             }
         }
-        free(cv);
-        /* upsampling -- :359-390: ufs = bilinear x2, skip_ufs = a second bilinear x2 */
-        ufs[l] = falloc((long)B * 2 * hw * 4);
-        orc_upsample_bilinear2x(fs[l], B * 2, h, w, ufs[l]);
-        skip_ufs[l] = falloc((long)B * 2 * hw * 16);
-        orc_upsample_bilinear2x(ufs[l], B * 2, 2 * h, 2 * w, skip_ufs[l]);
-        if (past_flow) {
-            ubfs[l] = falloc((long)B * 2 * hw * 4);
-            orc_upsample_bilinear2x(bfs[l], B * 2, h, w, ubfs[l]);
-            skip_ubfs[l] = falloc((long)B * 2 * hw * 16);
-            orc_upsample_bilinear2x(ubfs[l], B * 2, 2 * h, 2 * w, skip_ubfs[l]);
+        free(cv_fwd); free(cv_bwd); free(cv_join); free(cv_sum);
+        /* upsampling -- :359-390 (skip > 0): ufs = bilinear x2 [* 2 with rescale_flow];
+         * skip_ufs = l_st - 2 further bilinear x2 [* 2 each]                              */
+        for (int pass = 0; pass < 2; ++pass) {
+            float **src = pass ? bfs : fs, **u = pass ? ubfs : ufs, **sk = pass ? skip_ubfs : skip_ufs;
+            if (!src[l]) continue;
+            u[l] = falloc((long)B * 2 * hw * 4);
+            orc_upsample_bilinear2x(src[l], B * 2, h, w, u[l]);
+            if (o->rescale_flow) for (long i = 0; i < (long)B * 2 * hw * 4; ++i) u[l][i] = u[l][i] * 2.0f; /* :365-369 */
+            float *cur = u[l];
+            int ch_ = 2 * h, cw_ = 2 * w;
+            for (int i = 2; i <= L_ST - 1; ++i) { /* :377-389 */
+                float *nx = falloc((long)B * 2 * ch_ * cw_ * 4);
+                orc_upsample_bilinear2x(cur, B * 2, ch_, cw_, nx);
+                if (o->rescale_flow) for (long j = 0; j < (long)B * 2 * ch_ * cw_ * 4; ++j) nx[j] = nx[j] * 2.0f;
+                if (cur != u[l]) free(cur);
+                cur = nx; ch_ *= 2; cw_ *= 2;
+            }
+            sk[l] = cur;
         }
         /* warps -- :393-446 */
         for (int f = 1; f <= frames; ++f) {
             if (f == ref) continue;
-            if (l > L_ST) { /* :395-408: MulConstant(20*(f-ref)/2^(l-2)) */
-                const float k = (float)(20.0 * (f - ref) / pow(2, l - 2));
+            if (l > L_ST && f >= f_i && f <= l_i) { /* :395-408 */
+                const float k = o->rescale_flow ? (float)((double)o->flownet_factor * (f - ref))
+                                                : (float)((double)o->flownet_factor * (f - ref) / pow(2, l - 2));
                 ws[f][l - 1] = falloc((long)B * FEAT[l - 1] * hw * 4);
                 warping_unit(cs[f][l - 1], ufs[l], k, B, FEAT[l - 1], 2 * h, 2 * w, ws[f][l - 1]);
             }
-            /* :422-446: image warp with skip_u(b)fs, MulConstant(20*(f-ref)/2^(l-l_st)) */
-            const float *tmp = (past_flow && f < ref) ? skip_ubfs[l] : skip_ufs[l];
-            const float k2 = (float)(20.0 * (f - ref) / pow(2, l - L_ST));
-            iws[f][l] = falloc((long)B * 3 * hw * 16);
-            warping_unit(ds[f][l - L_ST + 1], tmp, k2, B, 3, 4 * h, 4 * w, iws[f][l]);
+            /* :422-446: image warp with skip_u(b)fs */
+            if (pruned && !(l == L_ST && f == 1 && !o->past_flow)) continue;
+            const float *tmp = (o->past_flow && f < ref) ? skip_ubfs[l] : skip_ufs[l];
+            const float k2 = o->rescale_flow ? (float)((double)o->flownet_factor * (f - ref))
+                                             : (float)((double)o->flownet_factor * (f - ref) / pow(2, l - L_ST));
+            const int uh = H >> (l - L_ST), uw = W >> (l - L_ST);
+            iws[f][l] = falloc((long)B * 3 * uh * uw);
+            warping_unit(ds[f][l - L_ST + 1], tmp, k2, B, 3, uh, uw, iws[f][l]);
         }
     }
 
     /* output table -- pwc.lua:459-489 */
     int no = 0;
     for (int l = L_ST; l <= LEVELS; ++l) {
-        const long n2 = (long)B * 2 * hh[l] * wl[l] * 16, n3 = (long)B * 3 * hh[l] * wl[l] * 16;
-        memcpy(outs[no++], skip_ufs[l], sizeof(float) * n2);
-        if (past_flow) memcpy(outs[no++], skip_ubfs[l], sizeof(float) * n2);
-        memcpy(outs[no++], skip_occs[l], sizeof(float) * n2);
-        memcpy(outs[no++], iws[1][l], sizeof(float) * n3);
-        memcpy(outs[no++], iws[3][l], sizeof(float) * n3);
+        const long px = (long)B * (H >> (l - L_ST)) * (W >> (l - L_ST));
+        if (skip_ufs[l] && (!pruned || l == L_ST)) memcpy(outs[no], skip_ufs[l], sizeof(float) * 2 * px);
+        ++no;
+        if (o->past_flow) { if (skip_ubfs[l]) memcpy(outs[no], skip_ubfs[l], sizeof(float) * 2 * px); ++no; }
+        if (skip_occs[l] && (!pruned || l == L_ST)) memcpy(outs[no], skip_occs[l], sizeof(float) * 2 * px);
+        ++no;
+        if (iws[1][l]) memcpy(outs[no], iws[1][l], sizeof(float) * 3 * px);
+        ++no;
+        if (iws[3][l]) memcpy(outs[no], iws[3][l], sizeof(float) * 3 * px);
+        ++no;
     }
 
     for (int f = 1; f <= frames; ++f) {
         free(Is[f]);
-        for (int k = 2; k <= 5; ++k) free(ds[f][k]);
-        for (int l = 2; l <= LEVELS; ++l) { free(cs[f][l]); free(ws[f][l]); free(iws[f][l]); }
+        for (int k = 2; k < 8; ++k) free(ds[f][k]);
+        for (int l = 2; l <= 7; ++l) { free(cs[f][l]); free(ws[f][l]); }
+        for (int l = 0; l < 9; ++l) free(iws[f][l]);
     }
-    for (int l = 0; l < 8; ++l) {
-        free(fs[l]); free(bfs[l]); free(ufs[l]); free(ubfs[l]); free(skip_ufs[l]);
-        free(skip_ubfs[l]); free(occs[l]); free(skip_occs[l]);
+    for (int l = 0; l < 9; ++l) {
+        if (skip_ufs[l] != ufs[l]) free(skip_ufs[l]);
+        if (skip_ubfs[l] != ubfs[l]) free(skip_ubfs[l]);
+        if (skip_occs[l] != uoccs[l]) free(skip_occs[l]);
+        free(fs[l]); free(bfs[l]); free(ufs[l]); free(ubfs[l]); free(occs[l]); free(uoccs[l]);
     }
     return no;
 }
 
-/* Sizes of the output table entries (channels and spatial size), same order. */
+/* The shipped graph (opts.lua:83-98): 20 (Hard) / 25 (Soft) output tensors. */
+ORC_API int orc_pwc_forward(const float *x, int B, int H, int W, const float *params,
+                            int past_flow, float **outs)
+{
+    orc_opts o;
+    orc_default_opts(&o, past_flow);
+    return orc_pwc_forward_ex(x, B, H, W, params, &o, outs);
+}
+
 ORC_API int orc_pwc_output_shapes(int H, int W, int past_flow, int *ch, int *oh, int *ow)
 {
-    int no = 0;
-    for (int l = L_ST; l <= LEVELS; ++l) {
-        const int h4 = (H >> (l - 1)) * 4, w4 = (W >> (l - 1)) * 4;
-        const int per = past_flow ? 5 : 4;
-        for (int j = 0; j < per; ++j) {
-            const int is_img = (j >= per - 2);
-            ch[no] = is_img ? 3 : 2; oh[no] = h4; ow[no] = w4; ++no;
-        }
-    }
-    return no;
+    orc_opts o;
+    orc_default_opts(&o, past_flow);
+    return orc_pwc_output_shapes_ex(H, W, &o, ch, oh, ow);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -40,8 +40,28 @@ def _f(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def param_count(past_flow):
-    return int(lib().orc_param_count(int(bool(past_flow))))
+class Opts(C.Structure):
+    """struct orc_opts of b2f_oracle.c: the option table of createModelMulti (pwc.lua:88-121)."""
+    _fields_ = [("win", C.c_int), ("levels", C.c_int), ("skip", C.c_int), ("two_frame", C.c_int),
+                ("sum_cvs", C.c_int), ("residual", C.c_int), ("occ_input", C.c_int), ("rescale_flow", C.c_int),
+                ("past_flow", C.c_int), ("flownet_factor", C.c_float), ("pruned", C.c_int)]
+
+
+def opts(past_flow=False, **kw):
+    """The shipped option set (opts.lua:83-98) with overrides, e.g. opts(win=5, levels=4) = createModelMulti(nil)."""
+    o = Opts()
+    lib().orc_default_opts(C.byref(o), int(bool(past_flow)))
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+def param_count(past_flow, o=None):
+    if o is None:
+        return int(lib().orc_param_count(int(bool(past_flow))))
+    lib().orc_param_count_ex.restype = C.c_long
+    return int(lib().orc_param_count_ex(C.byref(o)))
 
 
 def color_normalize(img):
@@ -144,23 +164,30 @@ def warping_unit(I, F, k):
     return out
 
 
-def output_shapes(H, W, past_flow):
-    ch = (C.c_int * 32)(); oh = (C.c_int * 32)(); ow = (C.c_int * 32)()
-    n = lib().orc_pwc_output_shapes(H, W, int(bool(past_flow)), ch, oh, ow)
+def output_shapes(H, W, past_flow, o=None):
+    ch = (C.c_int * 40)(); oh = (C.c_int * 40)(); ow = (C.c_int * 40)()
+    if o is None:
+        o = opts(past_flow)
+    n = lib().orc_pwc_output_shapes_ex(H, W, C.byref(o), ch, oh, ow)
     return [(ch[i], oh[i], ow[i]) for i in range(n)]
 
 
-def pwc_forward(x, params, past_flow):
-    """x: B x 9 x H x W normalized; returns the full output table (list)."""
+def pwc_forward(x, params, past_flow, o=None, pruned=False):
+    """x: B x 9 x H x W normalized; returns the full output table (list).  o: Opts (default: the shipped graph);
+    pruned: compute only what computeFlow reads (est[1], est[3]) -- the other entries come back as zeros."""
     x, xp = _f(x); params, pp = _f(params)
-    assert params.size == param_count(past_flow), (params.size, param_count(past_flow))
+    if o is None:
+        o = opts(past_flow)
+    o.pruned = int(bool(pruned))
+    assert params.size == param_count(past_flow, o), (params.size, param_count(past_flow, o))
     B, nine, H, W = x.shape
-    assert nine == 9 and H % 64 == 0 and W % 64 == 0
-    shapes = output_shapes(H, W, past_flow)
-    outs = [np.empty((B, c, h, w), np.float32) for (c, h, w) in shapes]
-    ptrs = (C.POINTER(C.c_float) * len(outs))(*[o.ctypes.data_as(C.POINTER(C.c_float)) for o in outs])
-    n = lib().orc_pwc_forward(xp, B, H, W, pp, int(bool(past_flow)), ptrs)
-    assert n == len(outs)
+    m = 1 << (o.levels - 1)
+    assert nine == 9 and H % m == 0 and W % m == 0
+    shapes = output_shapes(H, W, past_flow, o)
+    outs = [(np.zeros if pruned else np.empty)((B, c, h, w), np.float32) for (c, h, w) in shapes]
+    ptrs = (C.POINTER(C.c_float) * len(outs))(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in outs])
+    n = lib().orc_pwc_forward_ex(xp, B, H, W, pp, C.byref(o), ptrs)
+    assert n == len(outs), n
     return outs
 
 

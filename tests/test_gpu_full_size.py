@@ -3,6 +3,8 @@ box's host cores, so one triplet of every batch is compared against it (the end-
 whole batch is checked through size-independent properties of the path: determinism, batch-permutation equivariance
 (triplets are independent), single pass == batched pass, the occlusion softmax summing to one, and -- at the boundary
 -- the host-buffer entry point against the device-pointer one."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,18 +30,22 @@ def _run(torch, m, x):
 
 # BASELINE.json configs[1..4] (the last one is the per-GPU share, 16 triplets, of the 8-GPU batch of 128)
 @pytest.mark.parametrize("which,B,H,Wd", [("hard", 8, 256, 512), ("soft", 32, 384, 1280), ("soft", 8, 448, 1024), ("hard", 16, 1024, 1920)])
-def test_baseline_config_full_size(monkeypatch, which, B, H, Wd):
+def test_baseline_config_full_size(which, B, H, Wd):
+    """Library defaults, no option or environment override: exactly the kernel mix bench.py times (the Winograd variant
+    is a function of the map size only, so passes of any batch size agree bit for bit)."""
     import torch
     import bench
-    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", "4096")      # Winograd variant per map size only: passes of any batch size agree bit for bit
+    for k in os.environ:
+        assert not k.startswith("B2F_") or k == "B2F_LIB", "this test must run on the library defaults: unset " + k
     past = which == "soft"
     m = back2future.Model("random:%s:2:1.0" % which)
     try:
+        assert m.get_option("wino4_min_pixels") == 4096 and m.get_option("adaptive_kernels") == 0
         x = bench.make_triplets(torch, B, H, Wd, seed=11, device=torch.device("cuda", 0))
         torch.cuda.synchronize()
         flow, occ, est3 = _run(torch, m, x)
         assert bool(torch.isfinite(flow).all() and torch.isfinite(occ).all() and torch.isfinite(est3).all())
-        assert float(flow.abs().max()) > 1e-3
+        assert float(flow.abs().max()) > 0.02
         # occlusion probabilities: softmax over two channels (pwc.lua:308)
         assert float((occ.sum(1) - 1).abs().max()) <= 1e-6 and float(occ.min()) >= 0
         # determinism
@@ -67,5 +73,30 @@ def test_baseline_config_full_size(monkeypatch, which, B, H, Wd):
         e3 = est3[i].cpu().numpy().astype(np.float64)
         np.testing.assert_array_equal(fo[0], (e3[1] >= 0.6666).astype(np.uint8))
         np.testing.assert_array_equal(bo[0], (e3[0] >= 0.6666).astype(np.uint8))
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("B,H,Wd", [(16, 1024, 1920), (8, 256, 512)])
+def test_adaptive_kernel_selection_full_size(B, H, Wd):
+    """The opt-in per-launch Winograd selection (block rounds on the chip; results may differ from the default at the
+    1e-6 level and with the batch size): one triplet of a full batch against the oracle, same 1e-3 bar."""
+    import torch
+    import bench
+    m = back2future.Model("random:hard:2:1.0")
+    try:
+        m.set_option("adaptive_kernels", 1)
+        x = bench.make_triplets(torch, B, H, Wd, seed=11, device=torch.device("cuda", 0))
+        flow, occ, est3 = _run(torch, m, x)
+        assert float(flow.abs().max()) > 0.02
+        i = B // 3
+        xn = ((x[i:i + 1].cpu().numpy() + (-MEAN)) / STD).astype(np.float32)
+        table = O.pwc_forward(xn, W.random_init(2, False, 1.0), False)
+        d = np.abs(flow[i].cpu().numpy() - table[0][0])
+        assert d.max() <= 1e-3, d.max()
+        assert np.abs(occ[i].cpu().numpy() - table[1][0]).max() <= 1e-3
+        m.set_option("adaptive_kernels", 0)
+        flow0, occ0, _ = _run(torch, m, x)
+        assert float((flow0 - flow).abs().max()) <= 1e-4
     finally:
         m.close()

@@ -67,14 +67,14 @@ def test_conv3x3(hard, ci, co, stride, h, w, leaky):
 
 
 @pytest.mark.parametrize("ci,co,h,w", [(128, 128, 16, 30), (96, 64, 9, 17), (40, 96, 33, 20), (264, 128, 8, 16), (64, 68, 7, 9)])
-def test_conv3x3_f2x2_one_n_tile_per_block(hard, monkeypatch, ci, co, h, w):
+def test_conv3x3_f2x2_one_n_tile_per_block(hard, ci, co, h, w):
     """The F(2x2) kernel launched with one block per 32-output N tile (what small launches of wide layers use)."""
-    monkeypatch.setenv("B2F_OP_WINO_SPLIT", "1")
     r = _rng(ci + co)
     x = r.standard_normal((3, ci, h, w), dtype=np.float32)
     wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
     b = r.standard_normal(co, dtype=np.float32)
-    got = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(op_wino_split=1):
+        got = ops.conv3x3(hard, x, wt, b, 1, True)
     np.testing.assert_allclose(got, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=3e-5)
 
 
@@ -96,12 +96,12 @@ def test_conv3x3_transpose_detecting(hard):
         np.testing.assert_allclose(got, O.conv3x3(x, wt, np.zeros(68, np.float32), 1, False), rtol=0, atol=2e-5)
 
 
-@pytest.fixture(params=["0", "1"], ids=["corr-regular", "corr-latency-variant"])
-def corr_variant(request, monkeypatch):
+@pytest.fixture(params=[0, 1], ids=["corr-regular", "corr-latency-variant"])
+def corr_variant(request, hard):
     """Both instantiations of the warp + cost-volume kernel (the launcher would pick the latency variant for every
     test-sized launch)."""
-    monkeypatch.setenv("B2F_CORR_LAT", request.param)
-    return request.param
+    with hard.options(corr_variant=request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("C,h,w", [(32, 24, 40), (192, 4, 7), (96, 9, 17), (8, 1, 2), (64, 16, 16)])
@@ -206,19 +206,16 @@ def test_compute_flow_end_to_end(hard, soft, corr_variant, which, H, Wd):
     assert ((bo != ebo) & ~near[0:1]).sum() == 0
 
 
-@pytest.mark.parametrize("min_px", ["0", "1000000"])
-def test_compute_flow_either_winograd_kernel(hard, monkeypatch, min_px):
-    """The launcher picks F(4x4) or F(2x2) per launch by block count, which at test sizes means F(2x2) everywhere:
-    force every eligible layer of the graph onto the F(4x4) kernel (B2F_WINO4_MIN_PIXELS=0) and onto F(2x2) (1e6)."""
-    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", min_px)
+@pytest.mark.parametrize("min_px,adaptive", [(0, 0), (1000000, 0), (4096, 1)])
+def test_compute_flow_either_winograd_kernel(hard, min_px, adaptive):
+    """The launcher picks F(4x4) or F(2x2) per map size, which at test sizes means F(2x2) for most layers: force every
+    eligible layer of the graph onto the F(4x4) kernel (wino4_min_pixels = 0) and onto F(2x2) (1e6); the third case
+    is the opt-in per-launch rule (block rounds on the chip)."""
     r = _rng(12)
     H, Wd = 128, 256
     ims = _triplet(r, H, Wd)
-    hard.set_option("host_graph", 0)
-    try:
+    with hard.options(wino4_min_pixels=min_px, adaptive_kernels=adaptive, host_graph=0):
         flow, fo, bo = hard.computeFlow(*ims)
-    finally:
-        hard.set_option("host_graph", 1)
     eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
     d = np.abs(flow - eflow)
     assert np.abs(eflow).max() > 0.02 and d.max() <= 1e-3, d.max()
@@ -275,7 +272,7 @@ def test_compute_flow_boundary_bit_exact(hard, soft, which, H0, W0):
     np.testing.assert_array_equal(bo[0], (eocc[0] >= 0.6666).astype(np.uint8))
 
 
-def test_host_pipeline_many_sub_batches(soft, monkeypatch):
+def test_host_pipeline_many_sub_batches(soft):
     """b2f_compute_flow_batch cut into one-triplet sub-batches (5 of them through the two buffer sets, pageable
     and page-locked caller buffers): every triplet must equal its stand-alone computeFlow bit for bit."""
     import torch
@@ -284,16 +281,15 @@ def test_host_pipeline_many_sub_batches(soft, monkeypatch):
     trip = [_triplet(r, H0, W0) for _ in range(n)]
     im = [np.stack([t[i] for t in trip]) for i in range(3)]
     single = [soft.computeFlow(*t) for t in trip]
-    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(H0 * W0))
-    monkeypatch.setenv("B2F_HOST_THREADS", "3")
-    res = [soft.computeFlowBatch(*im)]
-    pin_in = [torch.from_numpy(a).pin_memory() for a in im]
-    pin_out = (torch.empty((n, 2, H0, W0), dtype=torch.float64).pin_memory(),
-               torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory(),
-               torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory())
-    res.append(soft.computeFlowBatch(*[t.numpy() for t in pin_in], out=tuple(t.numpy() for t in pin_out)))
-    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(2 * H0 * W0))      # 2 + 2 + 1
-    res.append(soft.computeFlowBatch(*im))
+    with soft.options(host_subbatch_pixels=H0 * W0, host_threads=3):
+        res = [soft.computeFlowBatch(*im)]
+        pin_in = [torch.from_numpy(a).pin_memory() for a in im]
+        pin_out = (torch.empty((n, 2, H0, W0), dtype=torch.float64).pin_memory(),
+                   torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory(),
+                   torch.empty((n, 1, H0, W0), dtype=torch.uint8).pin_memory())
+        res.append(soft.computeFlowBatch(*[t.numpy() for t in pin_in], out=tuple(t.numpy() for t in pin_out)))
+        soft.set_option("host_subbatch_pixels", 2 * H0 * W0)      # 2 + 2 + 1
+        res.append(soft.computeFlowBatch(*im))
     for fb, fob, bob in res:
         for i in range(n):
             np.testing.assert_array_equal(fb[i], single[i][0])
@@ -302,7 +298,7 @@ def test_host_pipeline_many_sub_batches(soft, monkeypatch):
 
 
 @pytest.mark.parametrize("H0,W0", [(64, 128), (67, 131)])
-def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
+def test_host_pipeline_8bit_transport_is_lossless(hard, H0, W0):
     """Inputs that are k / 255 (what image.load returns for 8-bit files) cross the link as bytes and are rebuilt on
     the device; the results must equal the float upload bit for bit -- also when a later triplet of the same call
     is not 8-bit data and the call falls back to floats from there on."""
@@ -312,11 +308,11 @@ def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
     trip = [_triplet(r, H0, W0) for _ in range(n)]
     trip = [[q(a) for a in t] if i != 3 else t for i, t in enumerate(trip)]     # triplet 3 keeps arbitrary floats
     im = [np.stack([t[i] for t in trip]) for i in range(3)]
-    monkeypatch.setenv("B2F_HOST_SUBBATCH_PIXELS", str(2 * H0 * W0))
-    monkeypatch.setenv("B2F_HOST_U8", "0")
+    hard.set_option("host_subbatch_pixels", 2 * H0 * W0)
+    hard.set_option("host_u8", 0)
     ref = hard.computeFlowBatch(*im)
     ref4 = hard.computeFlowBatch(*[a[:3] for a in im])
-    monkeypatch.setenv("B2F_HOST_U8", "1")
+    hard.set_option("host_u8", 1)
     got = hard.computeFlowBatch(*im)
     got4 = hard.computeFlowBatch(*[a[:3] for a in im])                          # all three triplets go as bytes
     for a, b in zip(ref + ref4, got + got4):
@@ -330,6 +326,7 @@ def test_host_pipeline_8bit_transport_is_lossless(hard, monkeypatch, H0, W0):
     pin = [torch.from_numpy(a).pin_memory() for a in by]
     for a, b in zip(ref4, hard.computeFlowBatch(*[t.numpy() for t in pin])):
         np.testing.assert_array_equal(a, b)
+    hard.set_option("host_subbatch_pixels", 16 << 20)
 
 
 def test_host_path_graph_replay_identical(soft):
@@ -493,11 +490,10 @@ def test_c_harness_matches_python_mirror(tmp_path, hard):
     np.testing.assert_array_equal(occ[1], ebo)
 
 
-def test_growing_shapes_match_a_fresh_context(monkeypatch):
+def test_growing_shapes_match_a_fresh_context():
     """A long-lived context whose workspace arena, buffer sets and graph cache keep growing must give the bits a
     fresh context gives for every shape (regression: the arena used to be zeroed by an asynchronous null-stream
     memset that could land on top of the first kernels' output after it grew)."""
-    monkeypatch.setenv("B2F_WINO4_MIN_PIXELS", "4096")     # kernel choice by map size only
     r = _rng(77)
     old = back2future.Model("random:soft:4:2.0")
     try:
@@ -535,3 +531,75 @@ def test_context_stream_is_ordered_with_the_default_stream(hard):
         hard.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), unit_input=True)
         hard.synchronize()
         assert torch.equal(flow, flow_ref)
+
+
+def test_set_weights_hard_to_soft_on_a_warm_context():
+    """b2f_set_weights on a context that has already captured hipGraphs for a shape: the Hard graphs (other packed
+    buffer, 3-channel est[3], no second softmax) must not be replayed for the Soft model."""
+    r = _rng(8)
+    ims = _triplet(r, 128, 192)
+    m = back2future.Model("random:hard:5:2.0")
+    fresh = back2future.Model("random:soft:6:2.0")
+    try:
+        for _ in range(3):                               # eager, capture, replay
+            h1 = m.computeFlow(*ims)
+        m.set_weights(W.random_init(6, True, 2.0))
+        assert m.past_flow
+        for _ in range(3):
+            got = m.computeFlow(*ims)
+            exp = fresh.computeFlow(*ims)
+            for a, b in zip(got, exp):
+                np.testing.assert_array_equal(a, b)
+        m.set_weights(W.random_init(5, False, 2.0))      # and back
+        for _ in range(3):
+            for a, b in zip(m.computeFlow(*ims), h1):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        m.close()
+        fresh.close()
+
+
+def test_broadcast_weights_device_path():
+    """The multi-GPU weight path on one GPU: a world-size-1 RCCL group, context B initialised from ANOTHER seed, the
+    flat buffer of A copied on the device into B's b2f_weights_device() buffer, RCCL broadcast in place on B's
+    buffer (dist.broadcast_weights), b2f_commit_weights -- B must then compute A's bits."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from back2future_amd import dist as D
+    r = _rng(9)
+    ims = _triplet(r, 128, 192)
+    a = back2future.Model("random:hard:5:2.0")
+    b = back2future.Model("random:hard:77:1.0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        exp = a.computeFlow(*ims)
+        before = b.computeFlow(*ims)
+        assert np.abs(before[0] - exp[0]).max() > 1e-3
+        assert D.weights_checksum(a) != D.weights_checksum(b)
+        pa, n = a.weights_device_ptr()
+        pb, nb = b.weights_device_ptr()
+        assert n == nb
+
+        def wrap(ptr):
+            class H(object):
+                pass
+            h = H()
+            h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            return torch.as_tensor(h, device=torch.device("cuda", 0))
+        wrap(pb).copy_(wrap(pa))                   # what a rank != src receives
+        torch.cuda.synchronize()
+        assert np.abs(b.computeFlow(*ims)[0] - before[0]).max() == 0      # packed copies still hold the old weights
+        assert D.broadcast_weights(b, src=0) == n   # in-place RCCL broadcast + commit
+        assert D.weights_checksum(a) == D.weights_checksum(b)
+        for x, y in zip(b.computeFlow(*ims), exp):
+            np.testing.assert_array_equal(x, y)
+    finally:
+        if created:
+            dist.destroy_process_group()
+        a.close()
+        b.close()
