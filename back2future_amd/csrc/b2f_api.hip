@@ -227,7 +227,7 @@ struct Plan {
     bool full;          // full model:forward table (all decoders, image pyramid, image warps)
     int rec;            // cost-volume record size in floats
     int h[8], w[8];
-    size_t img, tmp, cs[8], U[8], UB[8], cv, d[6], fs, bfs, logits, u2, flow_planar, ds[6], winfo, total;
+    size_t img, tmp, cs[8], U[8], UB[8], cv, d[6], fs, bfs, logits, u2, flow_planar, ds[6], total;
 };
 
 Plan make_plan(int B, int H, int W, bool full, bool past_flow)
@@ -245,7 +245,6 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     for (int l = 3; l <= 6; ++l) p.U[l] = take((size_t)B * p.h[l] * p.w[l] * 2);
     for (int l = 3; l <= 6; ++l) p.UB[l] = (full && past_flow) ? take((size_t)B * p.h[l] * p.w[l] * 2) : 0;
     p.cv = take((size_t)B * p.h[3] * p.w[3] * p.rec + 64);
-    p.winfo = take(corr_winfo_bytes(B, p.h[3], p.w[3]) / sizeof(float));   // per-tile source windows of the cost-volume kernel (largest level)
     const size_t px3 = (size_t)B * p.h[3] * p.w[3];
     for (int i = 1; i <= 5; ++i) p.d[i] = take(px3 * kDec[i]);
     p.fs = take(px3 * 8);       // conv outputs are chunk-planar: 2 channels live in one 8-float chunk
@@ -465,7 +464,6 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         cl.B = B; cl.C = Cl; cl.h = h; cl.w = w;
         cl.variant = c->corr_variant;
         cl.ablate = c->corr_ablate;
-        cl.winfo = A + P.winfo;
         {
             char cname[48];
             snprintf(cname, sizeof cname, c->profile_layers ? "warp_costvol_%dx%d" : "warp_costvol", h, w);
@@ -1028,9 +1026,8 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     HIPCHK(hipSetDevice(c->device));
     const int Cp = (C + 7) / 8 * 8;   // the fused kernel walks channels in chunks of 8; zero channels add 0
     const size_t hw = (size_t)h * w, nplanar = (size_t)B * C * hw, nn = (size_t)B * hw * Cp;
-    DevBuf dpl, dr, df, dpa, dfl_pl, dfl, dcv, dwi;
+    DevBuf dpl, dr, df, dpa, dfl_pl, dfl, dcv;
     CHK(dpl.alloc(nplanar)); CHK(dr.alloc(nn)); CHK(df.alloc(nn)); CHK(dpa.alloc(nn));
-    CHK(dwi.alloc(corr_winfo_bytes(B, h, w) / sizeof(float)));
     CHK(dcv.alloc((size_t)B * hw * kCvRec));
     const float *srcs[3] = {ref, nbr_future, nbr_past};
     float *dsts[3] = {dr.p, df.p, dpa.p};
@@ -1053,7 +1050,6 @@ int b2f_op_warp_costvol(b2f_ctx *c, const float *ref, const float *nbr_future, c
     cl.out_img_stride = (long)(hw * kCvRec); cl.out_chunk_stride = 8; cl.out_pix_stride = kCvRec;
     cl.B = B; cl.C = Cp; cl.h = h; cl.w = w;
     cl.variant = c->corr_variant;
-    cl.winfo = dwi.p;
     HIPCHK(launch_warp_costvol(cl, c->stream));
     std::vector<float> rec((size_t)B * hw * kCvRec);
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -100,10 +100,8 @@ struct CorrLaunch {
     int out_pix_stride;
     int B, C, h, w;
     int ablate = 0;                          // profiling only (option corr_ablate): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
-    int variant = -1;                        // -1 auto (= 2), 0 / 1 round-1 VALU kernels (regular / latency instantiation), 2 MFMA kernel; same bits
-    void *winfo = nullptr;                   // MFMA kernel: scratch for the per-tile source windows, corr_winfo_bytes() bytes (nullptr: VALU kernel)
+    int variant = -1;                        // -1 auto, 0 regular, 1 latency, 2 two-pixel instantiation (same arithmetic, same bits)
 };
-size_t corr_winfo_bytes(int B, int h, int w);
 #ifdef __HIPCC__
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one
 // contiguous range of logical work items instead (bijective for any grid size; placement only affects speed).
