@@ -45,6 +45,18 @@ SIGNATURES = {
                                    C.c_int, C.POINTER(C.c_int)]),
     "b2f_profile_reset": (C.c_int, [C.c_void_p]),
     "b2f_synchronize": (C.c_int, [C.c_void_p]),
+    "b2f_init_multi": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "b2f_destroy_multi": (None, [C.c_void_p]),
+    "b2f_multi_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    "b2f_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "b2f_multi_rebroadcast": (C.c_int, [C.c_void_p]),
+    "b2f_multi_weights_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
+    "b2f_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "b2f_multi_compute_flow_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int,
+                                               C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
+    "b2f_multi_compute_flow_batch_u8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
+                                                  C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "b2f_op_costvol": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_float_p]),
     "b2f_op_warp_bhwd": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

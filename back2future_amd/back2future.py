@@ -186,6 +186,69 @@ class Model(object):
             C.c_void_p(d_est3) if d_est3 else None, C.c_void_p(stream) if stream else None))
 
 
+class MultiModel(object):
+    """One process, several GPUs (b2f_init_multi): replaces nn.DataParallelTable of util.lua:27-48 for inference.  The
+    weights are loaded once and broadcast to every GPU's replica (RCCL / peer copy) inside the library; computeFlowBatch
+    splits the triplets contiguously over the GPUs."""
+
+    TRANSPORT = {0: "single GPU", 1: "RCCL broadcast", 2: "hipMemcpyPeer"}
+
+    def __init__(self, name="Ours-Soft-ft-KITTI", n_gpus=0, devices=None):
+        L = _lib.lib()
+        h = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices) if devices is not None else None
+        _lib.check(L.b2f_init_multi(name.encode() if name is not None else None, int(n_gpus), dv, C.byref(h)))
+        self._h = h
+        n, tr = C.c_int(), C.c_int()
+        devs = (C.c_int * 64)()
+        _lib.check(L.b2f_multi_info(h, C.byref(n), devs, 64, C.byref(tr)))
+        self.n_gpus, self.devices, self.transport = n.value, [devs[i] for i in range(n.value)], self.TRANSPORT[tr.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if _lib is not None:
+                _lib.lib().b2f_destroy_multi(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def weights_checksums(self):
+        sums = (C.c_ulonglong * self.n_gpus)()
+        _lib.check(_lib.lib().b2f_multi_weights_checksum(self._h, sums, self.n_gpus))
+        return [int(v) for v in sums]
+
+    def set_option(self, key, value):
+        for i in range(self.n_gpus):
+            _lib.check(_lib.lib().b2f_set_option(C.c_void_p(_lib.lib().b2f_multi_context(self._h, i)), key.encode(), int(value)))
+
+    def computeFlowBatch(self, im1, im2, im3):
+        as_bytes = all(np.asarray(a).dtype == np.uint8 for a in (im1, im2, im3))
+        if as_bytes:
+            im1, im2, im3 = (np.ascontiguousarray(a) for a in (im1, im2, im3))
+        else:
+            im1, im2, im3 = _lib.f32(im1), _lib.f32(im2), _lib.f32(im3)
+        n, _, H0, W0 = im1.shape
+        assert im1.shape == im2.shape == im3.shape and im1.shape[1] == 3, "expected three n x 3 x H x W arrays"
+        flow = np.empty((n, 2, H0, W0), np.float64)
+        fwd = np.empty((n, 1, H0, W0), np.uint8)
+        bwd = np.empty((n, 1, H0, W0), np.uint8)
+        outp = (flow.ctypes.data_as(C.POINTER(C.c_double)), fwd.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                bwd.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        if as_bytes:
+            u8p = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+            _lib.check(_lib.lib().b2f_multi_compute_flow_batch_u8(self._h, n, u8p(im1), u8p(im2), u8p(im3), H0, W0, *outp))
+        else:
+            _lib.check(_lib.lib().b2f_multi_compute_flow_batch(self._h, n, _lib.fptr(im1), _lib.fptr(im2), _lib.fptr(im3), H0, W0, *outp))
+        return flow, fwd, bwd
+
+
+def shard_range(n, rank, world):
+    """b2f_shard_range: [lo, hi) of `rank` when n triplets are split over `world` GPUs (util.lua:32)."""
+    lo, hi = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().b2f_shard_range(int(n), int(rank), int(world), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
 def init(opt=None, device=0):
     """back2future.init(opt) (back2future.lua:97-129): returns the computeFlow closure.
     The closure carries the model as `.model`."""

@@ -140,21 +140,35 @@ def make_triplets(torch, B, H, W, seed, device):
 
 
 def cpu_baseline(H, W, seed, n=2):
-    """Oracle (kind 'port') on the host cores, bounded sample: n triplets of the bench shape through the
-    full Ours-Hard graph (~415 GFLOP each at 1024x1920; ~6 s per triplet on the GPU box's 256 host cores)."""
+    """Both CPU columns time the SAME graph `value` runs -- the pruned computeFlow graph (365 GFLOP per 1024x1920 triplet)
+    -- on a bounded sample of n triplets of the bench shape, on the GPU box's host cores:
+      cpu_baseline        the oracle (oracle/b2f_oracle.c, kind 'port': literal restatement of the reference's loops,
+                          scalar direct convolution, OpenMP over (image, output channel)) -- a correctness tool, slow by design;
+      cpu_baseline_torch  the same graph in PyTorch-CPU (oneDNN convolutions, all threads): the closest stand-in for the
+                          reference's own CPU route, Torch7 nn:float()."""
     import numpy as np
+    import torch
     from back2future_amd import weights as Wt
-    from oracle import oracle as O
+    from oracle import oracle as O, torch_cpu as T
     rng = np.random.default_rng(seed)
     x = rng.random((n, 9, H, W), dtype=np.float32)
     params = Wt.random_init(2, False, 1.0)
     O.lib()
     t0 = time.perf_counter()
-    O.pwc_forward(x, params, False)
+    table = O.pwc_forward(x, params, False, pruned=True)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "triplets/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d triplets at 3x%dx%d, full Ours-Hard graph (model:forward), oracle/b2f_oracle.c with OpenMP "
-                      "on all host cores, %.2f s" % (n, H, W, dt)}
+    port = {"value": n / dt, "unit": "triplets/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d triplets at 3x%dx%d, pruned computeFlow graph of the Ours-Hard shape (the graph `value` runs), "
+                      "oracle/b2f_oracle.c with OpenMP on all host cores, %.2f s" % (n, H, W, dt)}
+    T.compute_flow_graph(x[:1], params, False)                       # untimed: oneDNN builds its primitives per shape on first use
+    t0 = time.perf_counter()
+    flow, occ = T.compute_flow_graph(x, params, False)
+    dt = time.perf_counter() - t0
+    tch = {"value": n / dt, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d triplets at 3x%dx%d, same pruned graph in PyTorch-CPU %s (oneDNN, fp32, %d threads), %.2f s; "
+                     "max |flow - oracle| %.1e" % (n, H, W, torch.__version__, torch.get_num_threads(), dt,
+                                                   float(np.abs(flow - table[0]).max()))}
+    return port, tch
 
 
 def pmc_traffic(B, H, W):
@@ -373,7 +387,7 @@ def main():
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(torch, model, H, W)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, 2)
+            out["cpu_baseline"], out["cpu_baseline_torch"] = cpu_baseline(H, W, 2)
         print(json.dumps(out), flush=True)
     model.close()
     if world > 1:

@@ -15,8 +15,9 @@
  * it into error(msg), mirroring THError at BilinearSamplerBHWD.cu:151-156).
  * Plain pointers and sizes only; the caller owns every buffer it passes in;
  * the library owns device memory inside the opaque context.  A context is
- * bound to one GPU (one process per GPU; multi-GPU = one context per rank with
- * the flat weight buffer broadcast over RCCL by the host, see b2f_weights_device).
+ * bound to one GPU; several GPUs of a node are driven either by one process per GPU
+ * (one context per rank, the host broadcasts the flat weight buffer over RCCL, see
+ * b2f_weights_device) or by one b2f_multi inside one process (b2f_init_multi below).
  * "host" pointers are CPU memory, "dev" pointers are HIP device memory on the
  * context's GPU.  `stream` is a hipStream_t passed as void* (NULL = the
  * context's own stream).
@@ -106,6 +107,36 @@ B2F_API int b2f_compute_flow_batch(b2f_ctx *ctx, int n, const float *im1, const 
 B2F_API int b2f_compute_flow_batch_u8(b2f_ctx *ctx, int n, const unsigned char *im1,
                               const unsigned char *im2, const unsigned char *im3, int H0, int W0,
                               double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
+
+/* ---- one node, several GPUs: replaces nn.DataParallelTable (util.lua:27-48) for this path ----
+ * One context per GPU inside the calling process, one library worker thread per GPU (the
+ * reference's replicas each run on their own thread, util.lua:34-40).  b2f_init_multi loads /
+ * generates the weights once (first device) and broadcasts them into the other replicas' device
+ * buffers with RCCL (ncclBroadcast, xGMI inside a node; dlopen'ed) or hipMemcpyPeer when RCCL is
+ * not loadable -- the NCCL parameter sync of train.lua:494-496.  devices: n_gpus ordinals or NULL
+ * (0 .. n_gpus-1); n_gpus = 0 takes every visible GPU.  The batch entry points split the n triplets
+ * statically and contiguously over the GPUs (b2f_shard_range: the dim-1 split of util.lua:32;
+ * sizes differ by at most one) and every GPU writes straight into its slice of the caller's
+ * buffers; same arguments and results as b2f_compute_flow_batch[_u8].                          */
+typedef struct b2f_multi b2f_multi;
+B2F_API int b2f_init_multi(const char *name_or_path, int n_gpus, const int *devices, b2f_multi **out);
+B2F_API void b2f_destroy_multi(b2f_multi *m);
+/* transport: 0 one GPU, 1 RCCL broadcast, 2 hipMemcpyPeer */
+B2F_API int b2f_multi_info(const b2f_multi *m, int *n_gpus, int *devices, int cap, int *transport);
+/* the i-th replica (for b2f_info / b2f_set_option / b2f_set_weights on replica 0 followed by
+ * b2f_multi_rebroadcast); NULL if out of range.  Owned by m.                                    */
+B2F_API b2f_ctx *b2f_multi_context(b2f_multi *m, int i);
+B2F_API int b2f_multi_rebroadcast(b2f_multi *m);
+/* FNV-1a of every replica's weight buffer as it sits on its GPU: equal after a broadcast        */
+B2F_API int b2f_multi_weights_checksum(b2f_multi *m, unsigned long long *sums, int cap);
+/* host-only: [lo, hi) of `rank` when n items are split over `world` GPUs                         */
+B2F_API int b2f_shard_range(int n, int rank, int world, int *lo, int *hi);
+B2F_API int b2f_multi_compute_flow_batch(b2f_multi *m, int n, const float *im1, const float *im2,
+                                 const float *im3, int H0, int W0, double *flow,
+                                 unsigned char *fwd_occ, unsigned char *bwd_occ);
+B2F_API int b2f_multi_compute_flow_batch_u8(b2f_multi *m, int n, const unsigned char *im1,
+                                    const unsigned char *im2, const unsigned char *im3, int H0, int W0,
+                                    double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
 
 /* ---- the hot path, device boundary: model:forward(imgs) (back2future.lua:74) ----
  * dev_in: B x 9 x H x W planar fp32 on the GPU (the tensor `imgs` of :73), H and W

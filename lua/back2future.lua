@@ -29,6 +29,11 @@ void b2f_destroy(b2f_ctx *ctx);
 int  b2f_info(const b2f_ctx *ctx, int *levels, int *win, int *past_flow, int *n_outputs, long long *n_params);
 int  b2f_compute_flow(b2f_ctx *ctx, const float *im1, const float *im2, const float *im3,
                       int H0, int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
+typedef struct b2f_multi b2f_multi;
+int  b2f_init_multi(const char *name_or_path, int n_gpus, const int *devices, b2f_multi **out);
+void b2f_destroy_multi(b2f_multi *m);
+int  b2f_multi_compute_flow_batch(b2f_multi *m, int n, const float *im1, const float *im2, const float *im3,
+                                  int H0, int W0, double *flow, unsigned char *fwd_occ, unsigned char *bwd_occ);
 ]]
 
 local lib = ffi.load(os.getenv('B2F_LIB') or 'libb2f.so')
@@ -83,5 +88,28 @@ local function init(opt)
    return computeFlow
 end
 M.init = init
+
+-- Several GPUs of one node (replaces nn.DataParallelTable, util.lua:27-48): initMulti(opt, nGPU) returns
+-- computeFlowBatch(im1, im2, im3) on n x 3 x H x W tensors; the n triplets are split over the GPUs by the
+-- library, the weights are broadcast to every GPU once (RCCL).  nGPU = 0: all visible GPUs.
+local function initMulti(opt, nGPU)
+   opt = opt or 'Ours-Soft-ft-KITTI'
+   local pm = ffi.new('b2f_multi*[1]')
+   check(lib.b2f_init_multi(opt, nGPU or 0, nil, pm))
+   local m = ffi.gc(pm[0], lib.b2f_destroy_multi)
+   return function(im1, im2, im3)
+      local a, b, c = im1:float():contiguous(), im2:float():contiguous(), im3:float():contiguous()
+      assert(a:dim() == 4 and a:size(2) == 3, 'expected n x 3 x H x W batches')
+      assert(a:isSameSizeAs(b) and a:isSameSizeAs(c), 'the three frame batches must have the same size')
+      local n, height, width = a:size(1), a:size(3), a:size(4)
+      local flow_est = torch.DoubleTensor(n, 2, height, width)
+      local fwd_occ_est = torch.ByteTensor(n, 1, height, width)
+      local bwd_occ_est = torch.ByteTensor(n, 1, height, width)
+      check(lib.b2f_multi_compute_flow_batch(m, n, a:data(), b:data(), c:data(), height, width,
+                                             flow_est:data(), fwd_occ_est:data(), bwd_occ_est:data()))
+      return flow_est, fwd_occ_est, bwd_occ_est
+   end
+end
+M.initMulti = initMulti
 
 return M

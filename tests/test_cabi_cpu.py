@@ -141,3 +141,21 @@ def test_integration_doc_prototypes_match_the_header():
     assert quoted, "no prototypes found in INTEGRATION.md"
     for name, proto in quoted.items():
         assert name in hdr and proto == hdr[name], (name, proto, hdr.get(name))
+
+
+def test_shard_range_matches_the_python_side():
+    """b2f_shard_range (the split b2f_multi_compute_flow_batch uses, host-only) against back2future_amd.dist.shard_range."""
+    from back2future_amd import dist as D
+    for n in (0, 1, 5, 16, 127, 128):
+        for world in (1, 2, 3, 8):
+            spans = [back2future.shard_range(n, r, world) for r in range(world)]
+            assert spans == [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+    with pytest.raises(_lib.B2FError):
+        back2future.shard_range(4, 2, 2)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_init_multi_fails_loudly_without_gpu():
+    with pytest.raises(_lib.B2FError, match="no HIP device"):
+        back2future.MultiModel("random:hard", n_gpus=1)

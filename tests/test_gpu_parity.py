@@ -603,3 +603,33 @@ def test_broadcast_weights_device_path():
             dist.destroy_process_group()
         a.close()
         b.close()
+
+
+def test_multi_gpu_entry_point_on_the_visible_gpus(monkeypatch):
+    """b2f_init_multi / b2f_multi_compute_flow_batch on every visible GPU (one on the test box): the sharded batch must
+    equal the single-context results bit for bit, and every replica must hold replica 0's weights.  With one GPU the
+    weight broadcast is still driven through RCCL (communicator of one rank, in-place ncclBroadcast)."""
+    import torch
+    if torch.cuda.device_count() == 1:
+        monkeypatch.setenv("B2F_MULTI_TRANSPORT", "selftest")
+    r = _rng(21)
+    n, H0, W0 = 5, 100, 150
+    ims = [r.random((n, 3, H0, W0), dtype=np.float32) for _ in range(3)]
+    mm = back2future.MultiModel("random:soft:5:2.0", n_gpus=0)
+    ref = back2future.Model("random:soft:5:2.0")
+    try:
+        assert mm.n_gpus == torch.cuda.device_count() >= 1
+        assert len(set(mm.weights_checksums())) == 1
+        assert mm.transport in ("RCCL broadcast", "hipMemcpyPeer"), mm.transport
+        got = mm.computeFlowBatch(*ims)
+        exp = ref.computeFlowBatch(*ims)
+        for a, b in zip(got, exp):
+            np.testing.assert_array_equal(a, b)
+        by = [np.round(a * 255).astype(np.uint8) for a in ims]
+        for a, b in zip(mm.computeFlowBatch(*by), ref.computeFlowBatch(*by)):
+            np.testing.assert_array_equal(a, b)
+        with pytest.raises(Exception):
+            back2future.MultiModel("random:hard", n_gpus=mm.n_gpus + 7)
+    finally:
+        mm.close()
+        ref.close()

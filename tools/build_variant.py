@@ -19,7 +19,7 @@ def main():
     subprocess.check_call([B.HIPCC] + B.FLAGS + B.EXTRA.get(src, []) + flags + ["-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj])
     objs = [obj if s == src else os.path.join(B.BUILD, os.path.splitext(s)[0] + ".o") for s in B.SOURCES]
     out = os.path.join(B.HERE, "libb2f_%s.so" % name)
-    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"])
     print(out)
 
 
