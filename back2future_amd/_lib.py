@@ -17,6 +17,7 @@ SIGNATURES = {
     "b2f_last_error": (C.c_char_p, []),
     "b2f_version": (C.c_int, []),
     "b2f_init": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "b2f_init_ex": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "b2f_destroy": (None, [C.c_void_p]),
     "b2f_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                            C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

@@ -32,10 +32,12 @@ def normalize(imgs):
 class Model(object):
     """Owns a b2f_ctx (the `model` global of back2future.lua:113)."""
 
-    def __init__(self, name="Ours-Soft-ft-KITTI", device=0):
+    def __init__(self, name="Ours-Soft-ft-KITTI", device=0, graph=None):
+        """graph: createModelMulti options other than the shipped ones, e.g. "win=5,levels=4" (b2f_init_ex)."""
         L = _lib.lib()
         h = C.c_void_p()
-        _lib.check(L.b2f_init(name.encode() if name is not None else None, int(device), C.byref(h)))
+        _lib.check(L.b2f_init_ex(name.encode() if name is not None else None, int(device),
+                                 graph.encode() if graph else None, C.byref(h)))
         self._h = h
         self.name = name
         self.device = int(device)

@@ -17,6 +17,18 @@ int api_fail(const std::string &m)
     return 1;
 }
 const std::string &api_error() { return g_err; }
+
+// All activations are chunk-planar: [image][C/8][h][w][8].
+ConvSeg cp8_seg(const float *ptr, int C, size_t hw)
+{
+    ConvSeg sgm;
+    sgm.ptr = ptr;
+    sgm.img_stride = (long)(hw * (size_t)((C + 7) / 8 * 8));
+    sgm.chunk_stride = (long)(hw * 8);
+    sgm.pix_stride = 8;
+    sgm.nchunks = 0;
+    return sgm;
+}
 }  // namespace b2f
 static int fail(const std::string &m) { return api_fail(m); }
 
@@ -130,7 +142,7 @@ int pack_all(b2f_ctx *c, const float *flat)
         else if (p.wino == 2) wino_choose_tiles(d.co, &p.nt, &p.nblk);
         else conv_choose_tiles(d.co, &p.nt, &p.nblk);
         std::vector<int> &m = maps[i];
-        if (d.kind != KIND_FEAT && d.idx == 1) {
+        if (d.kind != KIND_FEAT && d.idx == 1 && c->g.shipped()) {
             const int Cl = kFeat[d.level];
             const bool has_feat = d.ci >= kND + Cl;          // level-7 flow decoder takes the cost volume only
             const bool has_flow = d.ci == kND + Cl + 2;
@@ -267,9 +279,9 @@ void b2f::drop_graphs(b2f_ctx *c)
 }
 namespace {
 
-int ensure_workspace(b2f_ctx *c, const Plan &p)
+int ensure_workspace_floats(b2f_ctx *c, size_t total)
 {
-    if (p.total > c->arena_floats) {
+    if (total > c->arena_floats) {
         // rare (a larger shape than any before): full device syncs on both sides.  Earlier passes may have run on a
         // caller's stream, and hipMemset is asynchronous on the null stream, which the non-blocking streams the
         // kernels run on do not wait for -- without the second sync the memset could land on top of the first
@@ -281,27 +293,17 @@ int ensure_workspace(b2f_ctx *c, const Plan &p)
             c->arena_floats = 0;
             drop_graphs(c);
         }
-        HIPCHK(hipMalloc(&c->arena, p.total * sizeof(float)));
-        HIPCHK(hipMemset(c->arena, 0, p.total * sizeof(float)));
+        HIPCHK(hipMalloc(&c->arena, total * sizeof(float)));
+        HIPCHK(hipMemset(c->arena, 0, total * sizeof(float)));
         HIPCHK(hipDeviceSynchronize());
-        c->arena_floats = p.total;
+        c->arena_floats = total;
     }
     return 0;
 }
+int ensure_workspace(b2f_ctx *c, const Plan &p) { return ensure_workspace_floats(c, p.total); }
 
 // ---- one conv launch from the packed table -----------------------------------------------
 // All activations are chunk-planar: [image][C/8][h][w][8].
-ConvSeg cp8_seg(const float *ptr, int C, size_t hw)
-{
-    ConvSeg sgm;
-    sgm.ptr = ptr;
-    sgm.img_stride = (long)(hw * (size_t)((C + 7) / 8 * 8));
-    sgm.chunk_stride = (long)(hw * 8);
-    sgm.pix_stride = 8;
-    sgm.nchunks = 0;
-    return sgm;
-}
-
 int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *segs, int nimg, int H, int W,
              int stride, int leaky, float *out)
 {
@@ -519,6 +521,14 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
 }
 
 }  // namespace
+int b2f::find_conv_id(const b2f_ctx *c, int kind, int level, int idx) { return find_conv(c, kind, level, idx); }
+int b2f::run_conv_layer(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *segs, int nimg, int H, int W, int stride,
+                        int leaky, float *out)
+{
+    if (conv_id < 0) return fail("b2f: layer not present in this model");
+    return run_conv(c, s, cap, conv_id, segs, nimg, H, W, stride, leaky, out);
+}
+int b2f::ensure_arena(b2f_ctx *c, size_t floats) { return ensure_workspace_floats(c, floats); }
 int b2f::check_shape(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return fail("b2f: non-positive shape");
@@ -557,15 +567,18 @@ bool ends_with(const std::string &s, const char *suf)
 
 int install_weights(b2f_ctx *c, const float *flat, long long n, bool past)
 {
-    if (n != param_count(past)) return fail("b2f: weight count does not match the architecture");
+    GraphOpts g = c->g;
+    g.past_flow = past;
+    if (n != param_count(g)) return fail("b2f: weight count does not match the architecture");
     // captured graphs hold the packed-weight pointers and the Hard / Soft topology of the moment they were captured
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(c);
     if (c->w_dev && (c->nparams != n)) { HIPCHK(hipFree(c->w_dev)); c->w_dev = nullptr; }
     c->past_flow = past;
+    c->g = g;
     c->nparams = n;
     long long t = 0;
-    c->lay = weight_layout(past, &t);
+    c->lay = weight_layout(g, &t);
     if (!c->w_dev) HIPCHK(hipMalloc(&c->w_dev, (size_t)n * sizeof(float)));
     HIPCHK(hipMemcpy(c->w_dev, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     return pack_all(c, flat);
@@ -606,10 +619,17 @@ int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *
 }
 B2F_CATCH("b2f_load_t7")
 
-int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
+int b2f_init(const char *name_or_path, int device, b2f_ctx **out) { return b2f_init_ex(name_or_path, device, nullptr, out); }
+
+int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2f_ctx **out) try
 {
     if (!out) return fail("b2f_init: null out");
     *out = nullptr;
+    GraphOpts g;
+    {
+        std::string err;
+        if (!parse_graph_opts(graph_opts, g, err)) return fail("b2f_init: " + err);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("b2f_init: no HIP device available (this library has no CPU fallback)");
@@ -621,8 +641,9 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
     unsigned long long seed = 2;
     float gain = 1.f;
     if (parse_random(name, &past, &seed, &gain)) {
-        flat.resize((size_t)param_count(past));
-        random_weights(seed, past, gain, flat.data());
+        g.past_flow = past;
+        flat.resize((size_t)param_count(g));
+        random_weights(seed, g, gain, flat.data());
     } else {
         std::string path = name;
         if (path == "Ours-Hard") path = "models/RoamingImages_H.t7";                      // :100-102
@@ -630,6 +651,7 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
         else if (path == "Ours-Soft-ft-Sintel") path = "models/RoamingImages_H_Sintel_S.t7"; // :108-110
         if (ends_with(path, ".t7")) {
             std::string err;
+            if (!g.shipped()) return fail("b2f_init: graph options other than the shipped ones are read from random: / .b2fw weights only");
             if (!load_t7(path, flat, past, err)) return fail("b2f_init: " + err);
         } else if (ends_with(path, ".b2fw")) {
             FILE *f = fopen(path.c_str(), "rb");
@@ -641,15 +663,18 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
             const size_t rd = fread(flat.data(), 4, flat.size(), f);
             fclose(f);
             if (rd != flat.size()) return fail("b2f_init: short read on " + path);
-            if ((long long)flat.size() == param_count(true)) past = true;
-            else if ((long long)flat.size() == param_count(false)) past = false;
-            else return fail("b2f_init: " + path + " does not hold a Hard or Soft parameter set");
+            GraphOpts gp = g, gn = g;
+            gp.past_flow = true; gn.past_flow = false;
+            if ((long long)flat.size() == param_count(gp)) past = true;
+            else if ((long long)flat.size() == param_count(gn)) past = false;
+            else return fail("b2f_init: " + path + " does not hold a parameter set of this graph (with or without past-flow decoders)");
         } else {
             return fail(std::string("b2f_init: unknown model '") + name + "'");
         }
     }
     b2f_ctx *c = new b2f_ctx();
     c->device = device;
+    c->g = g;
     {   // defaults of the tuning options may come from the environment; read here once, never on the hot path
         auto env_int = [](const char *k, long long dflt) { const char *v = getenv(k); return v ? atoll(v) : dflt; };
         c->wino4_min_pixels = (int)env_int("B2F_WINO4_MIN_PIXELS", c->wino4_min_pixels);
@@ -675,7 +700,7 @@ int b2f_init(const char *name_or_path, int device, b2f_ctx **out) try
     *out = c;
     return 0;
 }
-B2F_CATCH("b2f_init")
+B2F_CATCH("b2f_init_ex")
 
 void b2f_destroy(b2f_ctx *c)
 {
@@ -703,10 +728,10 @@ void b2f_destroy(b2f_ctx *c)
 int b2f_info(const b2f_ctx *c, int *levels, int *win, int *past_flow, int *n_outputs, long long *n_params) try
 {
     if (!c) return fail("b2f_info: null context");
-    if (levels) *levels = kLevels;
-    if (win) *win = kWin;
+    if (levels) *levels = c->g.levels;
+    if (win) *win = c->g.win;
     if (past_flow) *past_flow = c->past_flow ? 1 : 0;
-    if (n_outputs) *n_outputs = (kLevels - kLst + 1) * (c->past_flow ? 5 : 4);   // pwc.lua:459-489
+    if (n_outputs) *n_outputs = c->g.n_outputs();   // pwc.lua:459-489
     if (n_params) *n_params = c->nparams;
     return 0;
 }
@@ -718,9 +743,11 @@ int b2f_set_weights(b2f_ctx *c, const float *host_flat, long long n) try
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     bool past;
-    if (n == param_count(true)) past = true;
-    else if (n == param_count(false)) past = false;
-    else return fail("b2f_set_weights: n is neither the Hard nor the Soft parameter count");
+    GraphOpts gp = c->g, gn = c->g;
+    gp.past_flow = true; gn.past_flow = false;
+    if (n == param_count(gp)) past = true;
+    else if (n == param_count(gn)) past = false;
+    else return fail("b2f_set_weights: n is neither the Hard nor the Soft parameter count of this graph");
     return install_weights(c, host_flat, n, past);
 }
 B2F_CATCH("b2f_set_weights")
@@ -850,6 +877,26 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
 {
     CHK(check_shape(B, H, W));
     HIPCHK(hipSetDevice(c->device));
+    if (!c->g.shipped()) {
+        // other graph shapes: the whole output table through the generic executor (b2f_graph.hip), then est[1] / the
+        // finest occlusion map / est[3] into the caller's buffers.  Synchronous, no hipGraph: a correctness path.
+        const int n = c->g.n_outputs(), per = c->past_flow ? 5 : 4, lst = c->g.l_st();
+        std::vector<float *> dev((size_t)n, nullptr);
+        int rc = 0;
+        for (int i = 0; i < n && !rc; ++i) {
+            const int l = lst + i / per, j = i % per;
+            const size_t cnt = (size_t)B * (H >> (l - lst)) * (W >> (l - lst)) * ((j >= per - 2) ? 3 : 2);
+            if (hipMalloc(&dev[(size_t)i], cnt * sizeof(float)) != hipSuccess) rc = fail("b2f_forward_device: out of device memory");
+        }
+        if (!rc) rc = graph_forward(c, s, false, dev_in, in_kind, B, H, W, dev.data());
+        const size_t n2 = (size_t)B * 2 * H * W * sizeof(float);
+        if (!rc && dev_flow && hipMemcpyAsync(dev_flow, dev[0], n2, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
+        if (!rc && dev_occ && hipMemcpyAsync(dev_occ, dev[(size_t)(c->past_flow ? 2 : 1)], n2, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
+        if (!rc && dev_est3 && hipMemcpyAsync(dev_est3, dev[2], c->past_flow ? n2 : n2 / 2 * 3, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
+        if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail("b2f_forward_device: synchronize failed");
+        for (float *p : dev) if (p) (void)hipFree(p);
+        return rc;
+    }
     const Plan P = make_plan(B, H, W, false, c->past_flow);
     CHK(ensure_workspace(c, P));
     Outs O;
@@ -899,13 +946,13 @@ int b2f_output_shapes(const b2f_ctx *c, int H, int W, int *ch, int *oh, int *ow,
 {
     if (!c) return fail("b2f_output_shapes: null context");
     int no = 0;
-    for (int l = kLst; l <= kLevels; ++l) {
+    for (int l = c->g.l_st(); l <= c->g.levels; ++l) {
         const int per = c->past_flow ? 5 : 4;
         for (int j = 0; j < per; ++j) {
             if (no >= cap) return fail("b2f_output_shapes: cap too small");
             ch[no] = (j >= per - 2) ? 3 : 2;
-            oh[no] = (H >> (l - 1)) * 4;
-            ow[no] = (W >> (l - 1)) * 4;
+            oh[no] = H >> (l - c->g.l_st());
+            ow[no] = W >> (l - c->g.l_st());
             ++no;
         }
     }
@@ -916,13 +963,19 @@ B2F_CATCH("b2f_output_shapes")
 int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, int n_outs) try
 {
     if (!c || !x || !outs) return fail("b2f_forward: null argument");
-    CHK(check_shape(B, H, W));
+    const bool shipped = c->g.shipped();
+    if (shipped) CHK(check_shape(B, H, W));
+    else if (B <= 0 || H <= 0 || W <= 0 || H % (1 << (c->g.levels - 1)) || W % (1 << (c->g.levels - 1)))
+        return fail("b2f_forward: H and W must be positive multiples of 2^(levels - 1)");
     HIPCHK(hipSetDevice(c->device));
-    const int per = c->past_flow ? 5 : 4;
-    if (n_outs != (kLevels - kLst + 1) * per) return fail("b2f_forward: n_outs must be 20 (Hard) or 25 (Soft)");
+    const int per = c->past_flow ? 5 : 4, lst = c->g.l_st(), lev = c->g.levels;
+    if (n_outs != c->g.n_outputs()) return fail("b2f_forward: n_outs must be (levels - skip) x 4 (5 with past-flow decoders): 20 / 25 for the shipped models");
     // arena first (it may be re-allocated), then the per-output device buffers
-    const Plan P = make_plan(B, H, W, true, c->past_flow);
-    CHK(ensure_workspace(c, P));
+    Plan P;
+    if (shipped) {
+        P = make_plan(B, H, W, true, c->past_flow);
+        CHK(ensure_workspace(c, P));
+    }
     std::vector<float *> dev(n_outs, nullptr);
     std::vector<size_t> cnt(n_outs, 0);
     float *d_in = nullptr;
@@ -933,8 +986,8 @@ int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, i
     };
     Outs O;
     int no = 0;
-    for (int l = kLst; l <= kLevels && !rc; ++l) {
-        const size_t px = (size_t)B * P.h[l] * P.w[l] * 16;
+    for (int l = lst; l <= lev && !rc; ++l) {
+        const size_t px = (size_t)B * (H >> (l - lst)) * (W >> (l - lst));
         for (int j = 0; j < per; ++j) {
             const int ch = (j >= per - 2) ? 3 : 2;
             cnt[no] = px * ch;
@@ -942,7 +995,7 @@ int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, i
             ++no;
         }
         if (rc) break;
-        int base = (l - kLst) * per, j = 0;
+        int base = (l - lst) * per, j = 0;
         O.t_ufs[l] = dev[base + j++];
         if (c->past_flow) O.t_ubfs[l] = dev[base + j++];
         O.t_occ[l] = dev[base + j++];
@@ -952,7 +1005,8 @@ int b2f_forward(b2f_ctx *c, const float *x, int B, int H, int W, float **outs, i
     const size_t nin = (size_t)B * 9 * H * W;
     if (!rc && hipMalloc(&d_in, nin * sizeof(float)) != hipSuccess) rc = fail("b2f_forward: out of device memory");
     if (!rc && hipMemcpyAsync(d_in, x, nin * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail("b2f_forward: H2D copy failed");
-    if (!rc) rc = forward_impl(c, c->stream, false, d_in, B2F_IN_NORMALIZED, P, O);
+    if (!rc) rc = shipped ? forward_impl(c, c->stream, false, d_in, B2F_IN_NORMALIZED, P, O)
+                          : graph_forward(c, c->stream, false, d_in, B2F_IN_NORMALIZED, B, H, W, dev.data());
     for (int i = 0; i < n_outs && !rc; ++i)
         if (hipMemcpyAsync(outs[i], dev[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail("b2f_forward: D2H copy failed");
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(std::string("b2f_forward: ") + hipGetErrorString(hipGetLastError()));

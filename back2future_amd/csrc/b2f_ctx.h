@@ -198,6 +198,7 @@ private:
 struct b2f_ctx {
     int device = 0;
     bool past_flow = false;
+    b2f::GraphOpts g;           // graph shape (createModelMulti options); g.past_flow == past_flow
     long long nparams = 0;
     hipStream_t stream = nullptr;
     std::vector<b2f::ConvDesc> lay;
@@ -262,4 +263,12 @@ void drop_graphs(b2f_ctx *c);
 // model:forward on device pointers, optionally replayed from a hipGraph (see b2f_api.hip)
 int forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow, float *dev_occ,
                    float *dev_est3, hipStream_t s, bool graph);
+// pieces of b2f_api.hip the generic graph executor (b2f_graph.hip) builds on
+ConvSeg cp8_seg(const float *ptr, int C, size_t hw);
+int find_conv_id(const b2f_ctx *c, int kind, int level, int idx);
+int run_conv_layer(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *segs, int nimg, int H, int W, int stride, int leaky,
+                   float *out);
+int ensure_arena(b2f_ctx *c, size_t floats);
+// b2f_graph.hip: model:forward for the non-shipped graph shapes; outs = the whole output table (planar device buffers)
+int graph_forward(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, int B, int H, int W, float *const *outs);
 }  // namespace b2f

@@ -21,17 +21,41 @@ LEVELS, L_ST, WIN = 7, 3, 9
 ND = 2 * WIN * WIN
 
 
-def occ_in_ch(l):
-    return ND + FEAT[l] + (2 if l != LEVELS else 0)
+SHIPPED = dict(win=9, levels=7, skip=2, two_frame=0, sum_cvs=0, residual=0, occ_input=0, rescale_flow=0, flownet_factor=20.0)
 
 
-def flow_in_ch(l):
-    return ND if l == LEVELS else ND + FEAT[l] + 2
+def graph_opts(**kw):
+    """createModelMulti option table (pwc.lua:88-121): the shipped values (opts.lua:83-98) with overrides."""
+    o = dict(SHIPPED)
+    for k, v in kw.items():
+        assert k in o, k
+        o[k] = v
+    return o
 
 
-def layout(past_flow):
+def opts_string(o):
+    """The graph_opts argument of b2f_init_ex for an option dict."""
+    return ",".join("%s=%g" % (k, float(v)) for k, v in o.items())
+
+
+def occ_in_ch(l, o=SHIPPED):
+    nd = o["win"] ** 2
+    n = (nd if o["two_frame"] else 2 * nd) + FEAT[l] + (FEAT[l] if o["two_frame"] else 0)
+    if l != o["levels"]:
+        n += 2 + (2 if o["occ_input"] else 0)
+    return n
+
+
+def flow_in_ch(l, o=SHIPPED):
+    nd = o["win"] ** 2
+    ndf = nd if (o["two_frame"] or o["sum_cvs"]) else 2 * nd
+    return ndf if l == o["levels"] else ndf + FEAT[l] + 2
+
+
+def layout(past_flow, o=SHIPPED):
     """List of (name, shape, offset) in canonical order."""
     out, off = [], 0
+    LEVELS, L_ST = o["levels"], o["skip"] + 1
 
     def add(name, shape):
         nonlocal off
@@ -42,9 +66,9 @@ def layout(past_flow):
         add("feat%d.conv1.w" % l, (FEAT[l], FEAT[l - 1], 3, 3)); add("feat%d.conv1.b" % l, (FEAT[l],))
         add("feat%d.conv2.w" % l, (FEAT[l], FEAT[l], 3, 3)); add("feat%d.conv2.b" % l, (FEAT[l],))
     for l in range(LEVELS, L_ST - 1, -1):
-        kinds = [("occ", occ_in_ch(l)), ("flow", flow_in_ch(l))]
+        kinds = [("occ", occ_in_ch(l, o)), ("flow", flow_in_ch(l, o))]
         if past_flow:
-            kinds.append(("past", flow_in_ch(l)))
+            kinds.append(("past", flow_in_ch(l, o)))
         for kind, n in kinds:
             ci = n
             for i, co in enumerate(DEC):
@@ -54,8 +78,8 @@ def layout(past_flow):
     return out, off
 
 
-def param_count(past_flow):
-    return layout(past_flow)[1]
+def param_count(past_flow, o=SHIPPED):
+    return layout(past_flow, o)[1]
 
 
 def _splitmix64(x):
@@ -75,10 +99,10 @@ def uniform01(seed, n, stream=0):
     return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / 16777216.0)
 
 
-def random_init(seed=2, past_flow=False, gain=1.0):
+def random_init(seed=2, past_flow=False, gain=1.0, o=SHIPPED):
     """nn.SpatialConvolution:reset() [3P]: weight and bias ~ U(-s, s), s = 1/sqrt(9*Ci);
     `gain` scales s (tests use gain > 1 so that flows are O(1) and warps matter)."""
-    lay, total = layout(past_flow)
+    lay, total = layout(past_flow, o)
     u = uniform01(seed, total)
     w = np.empty(total, np.float32)
     fan_in = None
@@ -91,7 +115,7 @@ def random_init(seed=2, past_flow=False, gain=1.0):
     return w
 
 
-def views(flat, past_flow):
-    lay, total = layout(past_flow)
+def views(flat, past_flow, o=SHIPPED):
+    lay, total = layout(past_flow, o)
     assert flat.size == total, (flat.size, total)
     return {name: flat[off:off + int(np.prod(shape))].reshape(shape) for name, shape, off in lay}

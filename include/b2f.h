@@ -58,10 +58,20 @@ B2F_API int b2f_version(void);
  *           (nn.SpatialConvolution:reset() distribution), for synthetic benchmarks.
  * device: HIP device ordinal.                                                    */
 B2F_API int b2f_init(const char *name_or_path, int device, b2f_ctx **out);
+/* Same with the graph shape of createModelMulti(opt) (models/pwc.lua:88-121) given explicitly, for models other
+ * than the shipped ones: graph_opts = "win=5,levels=4" (createModelMulti(nil), pwc.lua:88), or any subset of
+ * win (pwc_ws), levels, skip (pwc_skip, >= 1), two_frame, sum_cvs (pwc_sum_cvs), residual, occ_input,
+ * rescale_flow, flownet_factor; NULL / "" = the shipped graph (opts.lua:83-98).  frames = 3 and pwc_siamese = 1
+ * are fixed.  Weights: "random:hard|soft[:seed[:gain]]" or a .b2fw blob in the canonical order of that graph
+ * (feature units l = 2..levels, then l = levels..skip+1 {occ, flow, [past-flow] decoder}).  Non-shipped shapes run
+ * on a generic, untuned executor (every Lua node its own kernels); H and W of b2f_forward must then be multiples
+ * of 2^(levels-1), computeFlow keeps the reference's /64 rounding.                                            */
+B2F_API int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2f_ctx **out);
 B2F_API void b2f_destroy(b2f_ctx *ctx);
 
 /* levels (7), cost-volume window (9), past_flow (0 Hard / 1 Soft), number of
- * tensors in the model:forward output table (20 / 25, pwc.lua:459-489), #params. */
+ * tensors in the model:forward output table ((levels - skip) x 4 | 5: 20 / 25 for the shipped
+ * models, pwc.lua:459-489), #params. */
 B2F_API int b2f_info(const b2f_ctx *ctx, int *levels, int *win, int *past_flow, int *n_outputs,
              long long *n_params);
 

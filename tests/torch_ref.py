@@ -76,10 +76,14 @@ def _conv(x, w, b, stride=1, leaky=True):
     return F.leaky_relu(y, 0.2) if leaky else y
 
 
-def pwc_forward(x, wv, past_flow, dtype=torch.float64):
-    """models/pwc.lua createModelMulti with the shipped opts, in torch ops.
-    x: B x 9 x H x W numpy, wv: dict name->numpy (weights.views).  Returns the
-    output table as a list of numpy arrays plus a dict of intermediates."""
+def pwc_forward(x, wv, past_flow, dtype=torch.float64, o=None):
+    """models/pwc.lua createModelMulti(opt), in torch ops; o = option dict (back2future_amd.weights.graph_opts; default:
+    the shipped opts).  x: B x 9 x H x W numpy, wv: dict name->numpy (weights.views).  Returns the output table as a
+    list of numpy arrays plus a dict of intermediates."""
+    from back2future_amd import weights as Wt
+    o = o or Wt.SHIPPED
+    L, LST, win = o["levels"], o["skip"] + 1, o["win"]
+    ff = float(o["flownet_factor"])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     x = t(x)
     P = {k: t(v) for k, v in wv.items()}
@@ -87,12 +91,13 @@ def pwc_forward(x, wv, past_flow, dtype=torch.float64):
     ds = {}
     for f in (1, 3):
         ds[f] = {1: Is[f]}
-        for k in range(2, 6):
+        for k in range(2, L - LST + 2):
             ds[f][k] = F.avg_pool2d(ds[f][k - 1], 2)
+    frames = (2, 3) if o["two_frame"] else (1, 2, 3)
     cs = {}
-    for f in (1, 2, 3):
+    for f in frames:
         cs[f] = {1: Is[f]}
-        for l in range(2, 8):
+        for l in range(2, L + 1):
             a = _conv(cs[f][l - 1], P["feat%d.conv1.w" % l], P["feat%d.conv1.b" % l], 2)
             cs[f][l] = _conv(a, P["feat%d.conv2.w" % l], P["feat%d.conv2.b" % l], 1)
 
@@ -105,38 +110,62 @@ def pwc_forward(x, wv, past_flow, dtype=torch.float64):
     up = lambda a: F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
     nn2 = lambda a: F.interpolate(a, scale_factor=2, mode="nearest")
     ws = {1: {}, 3: {}}
-    fs, bfs, ufs, ubfs, sk_u, sk_ub, occs, sk_o, iws = {}, {}, {}, {}, {}, {}, {}, {}, {1: {}, 3: {}}
+    fs, bfs, ufs, ubfs, sk_u, sk_ub, occs, uoccs, sk_o, iws = {}, {}, {}, {}, {}, {}, {}, {}, {}, {1: {}, 3: {}}
     inter = {}
-    for l in range(7, 2, -1):
-        src = cs if l == 7 else ws
-        cvf = costvol_lua(cs[2][l], src[3][l], 9, True)
-        cvb = costvol_lua(cs[2][l], src[1][l], 9, False)
-        cv = torch.cat([cvf, cvb], 1)
-        inter["cv%d" % l] = cv
-        oin = [cv, cs[2][l]] + ([ufs[l + 1]] if l != 7 else [])
-        occs[l] = F.softmax(dec(torch.cat(oin, 1), l, "occ"), dim=1)
-        sk_o[l] = nn2(nn2(occs[l]))
-        if l == 7:
-            fs[l] = dec(cv, l, "flow")
-            if past_flow:
-                bfs[l] = dec(cv, l, "past")
+    for l in range(L, LST - 1, -1):
+        src = cs if l == L else ws
+        cvf = costvol_lua(cs[2][l], src[3][l], win, True)
+        if not o["two_frame"]:
+            cvb = costvol_lua(cs[2][l], src[1][l], win, False)
+            cv_occ = torch.cat([cvf, cvb], 1)
+            cv_flow = (cvf + cvb) if o["sum_cvs"] else cv_occ
         else:
-            fs[l] = dec(torch.cat([cv, cs[2][l], ufs[l + 1]], 1), l, "flow")
+            cv_occ = cv_flow = cvf
+        inter["cv%d" % l] = cv_occ
+        oin = [cv_occ, cs[2][l]] + ([cs[3][l]] if o["two_frame"] else [])
+        if l != L:
+            oin.append(ufs[l + 1])
+            if o["occ_input"]:
+                oin.append(uoccs[l + 1])
+        occs[l] = F.softmax(dec(torch.cat(oin, 1), l, "occ"), dim=1)
+        uoccs[l] = nn2(occs[l])
+        sk_o[l] = uoccs[l]
+        for _ in range(2, LST):
+            sk_o[l] = nn2(sk_o[l])
+        if l == L:
+            fs[l] = dec(cv_flow, l, "flow")
             if past_flow:
-                bfs[l] = dec(torch.cat([cv, cs[2][l], ubfs[l + 1]], 1), l, "past")
+                bfs[l] = dec(cv_flow, l, "past")
+        else:
+            fs[l] = dec(torch.cat([cv_flow, cs[2][l], ufs[l + 1]], 1), l, "flow")
+            if past_flow:
+                bfs[l] = dec(torch.cat([cv_flow, cs[2][l], ubfs[l + 1]], 1), l, "past")
+            if o["residual"]:
+                fs[l] = fs[l] + ufs[l + 1]
+                if past_flow:
+                    bfs[l] = bfs[l] + ubfs[l + 1]
         inter["fs%d" % l] = fs[l]
-        ufs[l] = up(fs[l]); sk_u[l] = up(ufs[l])
+        mul = 2.0 if o["rescale_flow"] else 1.0
+        ufs[l] = up(fs[l]) * mul
+        sk_u[l] = ufs[l]
+        for _ in range(2, LST):
+            sk_u[l] = up(sk_u[l]) * mul
         if past_flow:
-            ubfs[l] = up(bfs[l]); sk_ub[l] = up(ubfs[l])
+            ubfs[l] = up(bfs[l]) * mul
+            sk_ub[l] = ubfs[l]
+            for _ in range(2, LST):
+                sk_ub[l] = up(sk_ub[l]) * mul
         for f in (1, 3):
-            if l > 3:
-                ws[f][l - 1] = warp_gather(cs[f][l - 1], ufs[l] * (20.0 * (f - 2) / 2 ** (l - 2))).to(dtype)
+            if l > LST and f in frames:
+                k = ff * (f - 2) if o["rescale_flow"] else ff * (f - 2) / 2 ** (l - 2)
+                ws[f][l - 1] = warp_gather(cs[f][l - 1], ufs[l] * k).to(dtype)
             tmp = sk_ub[l] if (past_flow and f < 2) else sk_u[l]
-            iws[f][l] = warp_gather(ds[f][l - 2], tmp * (20.0 * (f - 2) / 2 ** (l - 3))).to(dtype)
+            k2 = ff * (f - 2) if o["rescale_flow"] else ff * (f - 2) / 2 ** (l - LST)
+            iws[f][l] = warp_gather(ds[f][l - LST + 1], tmp * k2).to(dtype)
     outs = []
-    for l in range(3, 8):
+    for l in range(LST, L + 1):
         outs.append(sk_u[l])
         if past_flow:
             outs.append(sk_ub[l])
         outs += [sk_o[l], iws[1][l], iws[3][l]]
-    return [o.numpy() for o in outs], {k: v.numpy() for k, v in inter.items()}
+    return [o_.numpy() for o_ in outs], {k: v.numpy() for k, v in inter.items()}
