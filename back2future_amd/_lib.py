@@ -62,6 +62,10 @@ SIGNATURES = {
                                  C.c_int, c_float_p]),
     "b2f_op_warp_bhwd": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, c_float_p]),
+    "b2f_op_warp_bhwd_backward": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, c_float_p, c_float_p]),
+    "b2f_op_costvol_backward": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, c_float_p, c_float_p]),
     "b2f_op_warp_costvol": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_float, C.c_int,
                                       C.c_int, C.c_int, C.c_int, c_float_p]),
     "b2f_op_conv3x3": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p,

@@ -67,3 +67,25 @@ def image_scale(model, src, Hd, Wd, normalize=False):
     dst = np.empty((Cc, Hd, Wd), np.float32)
     _lib.check(_lib.lib().b2f_op_image_scale(_h(model), _lib.fptr(src), Cc, Hs, Ws, int(normalize), _lib.fptr(dst), Hd, Wd))
     return dst
+
+
+def warp_bhwd_backward(model, img, grid, grad_out, only_grid=False):
+    """BilinearSamplerBHWD:updateGradInput: returns (grad_img or None, grad_grid)."""
+    img, grid, grad_out = _lib.f32(img), _lib.f32(grid), _lib.f32(grad_out)
+    B, ih, iw, Cc = img.shape
+    _, gh, gw, _two = grid.shape
+    gi = None if only_grid else np.empty_like(img)
+    gg = np.empty_like(grid)
+    _lib.check(_lib.lib().b2f_op_warp_bhwd_backward(_h(model), _lib.fptr(img), _lib.fptr(grid), _lib.fptr(grad_out), B, ih, iw, Cc,
+                                                     gh, gw, _lib.fptr(gi) if gi is not None else None, _lib.fptr(gg)))
+    return gi, gg
+
+
+def costvol_backward(model, ref, frm, grad_out, win=9, fwd=True):
+    """CostVolMulti:updateGradInput for {ref, frm}: returns (grad_ref, grad_frm)."""
+    ref, frm, grad_out = _lib.f32(ref), _lib.f32(frm), _lib.f32(grad_out)
+    B, Cc, h, w = ref.shape
+    gr, gf = np.empty_like(ref), np.empty_like(frm)
+    _lib.check(_lib.lib().b2f_op_costvol_backward(_h(model), _lib.fptr(ref), _lib.fptr(frm), _lib.fptr(grad_out), B, Cc, h, w, win,
+                                                   int(bool(fwd)), _lib.fptr(gr), _lib.fptr(gf)))
+    return gr, gf

@@ -199,6 +199,18 @@ B2F_API int b2f_op_costvol(b2f_ctx *ctx, const float *ref, const float *frm, int
  * B x gh x gw x 2 (x first), out: B x gh x gw x C.                                  */
 B2F_API int b2f_op_warp_bhwd(b2f_ctx *ctx, const float *img, const float *grid, int B, int ih,
                      int iw, int C, int gh, int gw, float *out);
+/* Backward passes of the two custom modules (training side; not used by computeFlow).
+ * nn.BilinearSamplerBHWD:updateGradInput -- BilinearSamplerBHWD.lua:81-107, CUDA kernel
+ * BilinearSamplerBHWD.cu:161-307: grad_out B x gh x gw x C -> grad_img B x ih x iw x C (zeroed, then
+ * accumulated; NULL = the onlyGrid instantiation, :372-421) and grad_grid B x gh x gw x 2 (x first).      */
+B2F_API int b2f_op_warp_bhwd_backward(b2f_ctx *ctx, const float *img, const float *grid,
+                              const float *grad_out, int B, int ih, int iw, int C, int gh, int gw,
+                              float *grad_img, float *grad_grid);
+/* nn.CostVolMulti(win, fwd):updateGradInput({ref, frm}, grad_out) -- models/CostVolMulti.lua:111-181:
+ * grad_out B x win*win x h x w -> grad_ref, grad_frm B x C x h x w.                                       */
+B2F_API int b2f_op_costvol_backward(b2f_ctx *ctx, const float *ref, const float *frm,
+                            const float *grad_out, int B, int C, int h, int w, int win, int fwd,
+                            float *grad_ref, float *grad_frm);
 /* The fused kernel the pipeline uses for pwc.lua:246-267 + :393-409: warp both
  * neighbour maps by +k*flow (future) / -k*flow (past) and emit the joined
  * 162-channel cost volume.  ref/nbr_future/nbr_past: B x C x h x w; flow: B x 2 x h x w

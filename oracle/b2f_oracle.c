@@ -377,6 +377,113 @@ ORC_API void orc_warping_unit(const float *I, const float *F, float k, int B, in
 }
 
 /* ------------------------------------------------------------------------- */
+/* Backward passes (not on the computeFlow path -- training only).
+ *
+ * nn.BilinearSamplerBHWD:updateGradInput, CUDA kernel backwardBilinearSampling<onlyGrid>
+ * (extras/stnbhwd/BilinearSamplerBHWD.cu:161-307; Lua side BilinearSamplerBHWD.lua:81-107
+ * zeroes both gradInputs first).  Per output pixel: the four taps' weights from getTopLeft
+ * (:199-202); every channel's gradOutput is scattered into gradInputImages with the tap
+ * weights (atomicAdd, :236-259; skipped when grad_img == NULL = the onlyGrid instantiation);
+ * the four dot products <input tap, gradOutput> are accumulated by 32 threads striding the
+ * channels (:231) and summed by the shared-memory tree of sumReduceShMem (:27-36), restated
+ * here in the same association; grid gradient :289-290, stored x first (:296-297).
+ * The atomic accumulation order of the reference is not defined; this restatement adds in
+ * (yOut, xOut, channel) order.                                                            */
+ORC_API void orc_warp_bhwd_backward(const float *img, const float *grid, const float *grad_out,
+                                    int B, int ih, int iw, int C, int gh, int gw,
+                                    float *grad_img, float *grad_grid)
+{
+    if (grad_img) memset(grad_img, 0, sizeof(float) * (size_t)B * ih * iw * C);
+    for (int b = 0; b < B; ++b)
+        for (int yOut = 0; yOut < gh; ++yOut)
+            for (int xOut = 0; xOut < gw; ++xOut) {
+                const float *g = grid + (((long)b * gh + yOut) * gw + xOut) * 2;
+                float xc = g[0] + xOut;
+                if (xc < 0) xc = 0;
+                if (xc > (iw - 1)) xc = iw - 1;
+                const int xl = (int)floorf(xc);
+                const float xw = 1 - (xc - xl);
+                float yc = g[1] + yOut;
+                if (yc < 0) yc = 0;
+                if (yc > (ih - 1)) yc = ih - 1;
+                const int yt = (int)floorf(yc);
+                const float yw = 1 - (yc - yt);
+                const int tl_in = xl >= 0 && xl <= iw - 1 && yt >= 0 && yt <= ih - 1;
+                const int tr_in = xl + 1 >= 0 && xl + 1 <= iw - 1 && yt >= 0 && yt <= ih - 1;
+                const int bl_in = xl >= 0 && xl <= iw - 1 && yt + 1 >= 0 && yt + 1 <= ih - 1;
+                const int br_in = xl + 1 >= 0 && xl + 1 <= iw - 1 && yt + 1 >= 0 && yt + 1 <= ih - 1;
+                const long tl = (((long)b * ih + yt) * iw + xl) * C;
+                const long tr = tl + C, bl = tl + (long)iw * C, br = bl + C;
+                const float *go = grad_out + (((long)b * gh + yOut) * gw + xOut) * C;
+                float part[4][32];
+                memset(part, 0, sizeof part);
+                for (int tx = 0; tx < 32; ++tx)
+                    for (int t = tx; t < C; t += 32) {
+                        const float gv = go[t];
+                        if (tl_in) { part[0][tx] += img[tl + t] * gv; if (grad_img) grad_img[tl + t] += xw * yw * gv; }
+                        if (tr_in) { part[1][tx] += img[tr + t] * gv; if (grad_img) grad_img[tr + t] += (1 - xw) * yw * gv; }
+                        if (bl_in) { part[2][tx] += img[bl + t] * gv; if (grad_img) grad_img[bl + t] += xw * (1 - yw) * gv; }
+                        if (br_in) { part[3][tx] += img[br + t] * gv; if (grad_img) grad_img[br + t] += (1 - xw) * (1 - yw) * gv; }
+                    }
+                float dot[4];
+                for (int k = 0; k < 4; ++k) {
+                    float *sh = part[k];
+                    for (int st = 16; st >= 1; st >>= 1)
+                        for (int i = 0; i < st; ++i) sh[i] = sh[i] + sh[i + st];
+                    dot[k] = sh[0];
+                }
+                const float yf = -xw * dot[0] + xw * dot[2] - (1 - xw) * dot[1] + (1 - xw) * dot[3];
+                const float xf = -yw * dot[0] + yw * dot[1] - (1 - yw) * dot[2] + (1 - yw) * dot[3];
+                float *gg = grad_grid + (((long)b * gh + yOut) * gw + xOut) * 2;
+                gg[0] = xf;
+                gg[1] = yf;
+            }
+}
+
+/* nn.CostVolMulti:updateGradInput -- models/CostVolMulti.lua:111-181, loop for loop (two
+ * input frames, as pwc.lua always passes): gradInputs zeroed (:124-126); for every
+ * displacement i (q_x_ outer, q_y_ inner, :135-136), go = gradOutput[:, i, qy, qx] repeated
+ * over the N channels (:160-161), gradInputRef[qy, qx] += go .* frame[py, px] (:163),
+ * gradInputFrame[py, px] += go .* ref[qy, qx] (:164); both divided by N (frames - 1) (:175-177). */
+ORC_API void orc_costvol_backward(const float *ref, const float *frame, const float *grad_out,
+                                  int B, int N, int h, int w, int win, int fwd,
+                                  float *grad_ref, float *grad_frame)
+{
+    const int n = (win - 1) / 2;
+    const long hw = (long)h * w;
+    memset(grad_ref, 0, sizeof(float) * (size_t)B * N * hw);
+    memset(grad_frame, 0, sizeof(float) * (size_t)B * N * hw);
+    int i = 0;
+    for (int q_x_ = -n; q_x_ <= n; ++q_x_)
+        for (int q_y_ = -n; q_y_ <= n; ++q_y_) {
+            int q_x = q_x_, q_y = q_y_;
+            if (!fwd) { q_x = -q_x; q_y = -q_y; }
+            int qx0 = q_x, qx1 = w, px0 = 0;
+            if (q_x < 0) { qx0 = 0; qx1 = w + q_x; px0 = -q_x; }
+            int qy0 = q_y, qy1 = h, py0 = 0;
+            if (q_y < 0) { qy0 = 0; qy1 = h + q_y; py0 = -q_y; }
+            if (qx1 > qx0 && qy1 > qy0) {
+                for (int b = 0; b < B; ++b) {
+                    const float *go = grad_out + ((long)b * win * win + i) * hw;
+                    for (int k = 0; k < N; ++k) {
+                        const float *r = ref + ((long)b * N + k) * hw, *g = frame + ((long)b * N + k) * hw;
+                        float *gr = grad_ref + ((long)b * N + k) * hw, *gf = grad_frame + ((long)b * N + k) * hw;
+                        for (int y = qy0; y < qy1; ++y)
+                            for (int x = qx0; x < qx1; ++x) {
+                                const long q = (long)y * w + x, pp = (long)(y - qy0 + py0) * w + (x - qx0 + px0);
+                                gr[q] += go[q] * g[pp];
+                                gf[pp] += go[q] * r[q];
+                            }
+                    }
+                }
+            }
+            ++i;
+        }
+    const float div = (float)N;
+    for (long j = 0; j < (long)B * N * hw; ++j) { grad_ref[j] = grad_ref[j] / div; grad_frame[j] = grad_frame[j] / div; }
+}
+
+/* ------------------------------------------------------------------------- */
 /* createModelMulti(opt) of models/pwc.lua:87-508, every branch the option table
  * selects (frames = 3, pwc_siamese = 1 and pwc_skip >= 1 are fixed: the only values
  * the reference's CostVolMulti call sites / shipped models use).

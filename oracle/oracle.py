@@ -156,6 +156,31 @@ def warp_bhwd(img, grid):
     return out
 
 
+def warp_bhwd_backward(img, grid, grad_out, only_grid=False):
+    """BilinearSamplerBHWD:updateGradInput (CUDA kernel); returns (grad_img or None, grad_grid)."""
+    img, ip = _f(img); grid, gp = _f(grid); grad_out, op = _f(grad_out)
+    B, ih, iw, c = img.shape
+    _, gh, gw, _two = grid.shape
+    assert grad_out.shape == (B, gh, gw, c)
+    gi = None if only_grid else np.empty_like(img)
+    gg = np.empty_like(grid)
+    lib().orc_warp_bhwd_backward(ip, gp, op, B, ih, iw, c, gh, gw,
+                                 gi.ctypes.data_as(C.POINTER(C.c_float)) if gi is not None else None,
+                                 gg.ctypes.data_as(C.POINTER(C.c_float)))
+    return gi, gg
+
+
+def costvol_backward(ref, frm, grad_out, win=9, fwd=True):
+    """CostVolMulti:updateGradInput for {ref, frm}: returns (grad_ref, grad_frm)."""
+    ref, rp = _f(ref); frm, fp = _f(frm); grad_out, gp = _f(grad_out)
+    B, N, h, w = ref.shape
+    assert grad_out.shape == (B, win * win, h, w)
+    gr, gf = np.empty_like(ref), np.empty_like(frm)
+    lib().orc_costvol_backward(rp, fp, gp, B, N, h, w, win, int(bool(fwd)),
+                               gr.ctypes.data_as(C.POINTER(C.c_float)), gf.ctypes.data_as(C.POINTER(C.c_float)))
+    return gr, gf
+
+
 def warping_unit(I, F, k):
     I, ip = _f(I); F, fp = _f(F)
     B, c, h, w = I.shape

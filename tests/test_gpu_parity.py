@@ -633,3 +633,33 @@ def test_multi_gpu_entry_point_on_the_visible_gpus(monkeypatch):
     finally:
         mm.close()
         ref.close()
+
+
+@pytest.mark.parametrize("C,h,w,scale", [(3, 9, 11, 1.5), (40, 7, 13, 3.0), (128, 6, 5, 0.4), (32, 1, 4, 2.0)])
+def test_warp_bhwd_backward(hard, C, h, w, scale):
+    """BilinearSamplerBHWD:updateGradInput (BilinearSamplerBHWD.cu:161-307) vs the oracle: the grid gradient reduces in
+    the reference's own order (bit-exact), the image gradient is an atomic scatter (order-free tolerance)."""
+    r = _rng(C * h + w)
+    img = r.standard_normal((2, h, w, C), dtype=np.float32)
+    grid = (r.standard_normal((2, h, w, 2)) * scale).astype(np.float32)       # incl. points clamped at the border
+    go = r.standard_normal((2, h, w, C), dtype=np.float32)
+    gi, gg = ops.warp_bhwd_backward(hard, img, grid, go)
+    ei, eg = O.warp_bhwd_backward(img, grid, go)
+    np.testing.assert_array_equal(gg, eg)
+    np.testing.assert_allclose(gi, ei, rtol=1e-5, atol=1e-5)
+    gi2, gg2 = ops.warp_bhwd_backward(hard, img, grid, go, only_grid=True)
+    assert gi2 is None
+    np.testing.assert_array_equal(gg2, eg)
+
+
+@pytest.mark.parametrize("C,h,w,win,fwd", [(6, 10, 12, 9, True), (6, 10, 12, 9, False), (32, 7, 5, 5, True), (8, 3, 4, 3, False), (16, 1, 9, 9, True)])
+def test_costvol_backward(hard, C, h, w, win, fwd):
+    """CostVolMulti:updateGradInput (CostVolMulti.lua:111-181): same sequence of fp32 operations as the Lua loops."""
+    r = _rng(C + h * w + win)
+    ref = r.standard_normal((2, C, h, w), dtype=np.float32)
+    frm = r.standard_normal((2, C, h, w), dtype=np.float32)
+    go = r.standard_normal((2, win * win, h, w), dtype=np.float32)
+    gr, gf = ops.costvol_backward(hard, ref, frm, go, win, fwd)
+    er, ef = O.costvol_backward(ref, frm, go, win, fwd)
+    np.testing.assert_array_equal(gr, er)
+    np.testing.assert_array_equal(gf, ef)
