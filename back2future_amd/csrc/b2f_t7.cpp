@@ -104,7 +104,14 @@ struct Reader {
             case 1: o->kind = Obj::NUM; o->num = f64(); return o;
             case 2: o->kind = Obj::STR; o->str = str(); return o;
             case 5: o->kind = Obj::BOOL; o->b = i32() != 0; return o;
-            case 3: case 4: case 6: case 7: case 8: break;
+            case 6:
+                // TYPE_FUNCTION (legacy, torch7 File.lua [3P]): no reference index -- int32 size, dumped chunk, then the
+                // upvalues object.  Not needed, but must be consumed with the right framing.
+                o->kind = Obj::FUNC;
+                (void)str();
+                (void)object(depth + 1);
+                return o;
+            case 3: case 4: case 7: case 8: break;
             default: ok = false; err = "unknown type tag " + std::to_string(tag); return o;
         }
         const int idx = i32();
@@ -163,7 +170,7 @@ struct Reader {
             o->payload = object(depth + 1);   // the table of fields
             return o;
         }
-        // functions: dumped bytecode string + upvalue table; not needed, but must be consumed
+        // TYPE_RECUR_FUNCTION (8) / LEGACY_RECUR_FUNCTION (7): indexed like tables; dumped chunk + upvalue table
         o->kind = Obj::FUNC;
         (void)str();
         (void)object(depth + 1);

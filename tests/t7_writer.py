@@ -38,9 +38,22 @@ class TorchObj(object):
         self.cls, self.fields = cls, dict(fields)
 
 
+class Function(object):
+    """A serialized Lua function: tag 6 (TYPE_FUNCTION: size, dumped chunk, upvalues -- no reference index), 7
+    (LEGACY_RECUR_FUNCTION) or 8 (TYPE_RECUR_FUNCTION): reference index, size, dumped chunk, upvalue table."""
+    def __init__(self, tag, upvalues=None):
+        self.tag, self.upvalues = tag, upvalues if upvalues is not None else {}
+
+
 class Writer(object):
-    def __init__(self, f):
-        self.f, self.ids, self.next = f, {}, 1
+    def __init__(self, f, versioned=True):
+        """versioned=False writes torch objects the pre-"V 1" way (class name string only)."""
+        self.f, self.ids, self.next, self.versioned = f, {}, 1, versioned
+
+    def header(self, cls):
+        if self.versioned:
+            self.string("V 1")
+        self.string(cls)
 
     def i32(self, v): self.f.write(struct.pack("<i", int(v)))
     def i64(self, v): self.f.write(struct.pack("<q", int(v)))
@@ -81,12 +94,12 @@ class Writer(object):
         elif isinstance(o, Storage):
             self.i32(4)
             if self.ref(o): return
-            self.string("V 1"); self.string(o.cls)
+            self.header(o.cls)
             self.i64(o.arr.size); self.f.write(o.arr.tobytes())
         elif isinstance(o, Tensor):
             self.i32(4)
             if self.ref(o): return
-            self.string("V 1"); self.string(o.cls)
+            self.header(o.cls)
             self.i32(len(o.size))
             for s in o.size: self.i64(s)
             for s in o.stride: self.i64(s)
@@ -95,8 +108,13 @@ class Writer(object):
         elif isinstance(o, TorchObj):
             self.i32(4)
             if self.ref(o): return
-            self.string("V 1"); self.string(o.cls)
+            self.header(o.cls)
             self.obj(o.fields)
+        elif isinstance(o, Function):
+            self.i32(o.tag)
+            if o.tag != 6 and self.ref(o): return
+            self.string("\x1bLuaQ-not-a-real-chunk\x00\x01\x02")
+            self.obj(o.upvalues)
         else:
             raise TypeError(type(o))
 
@@ -217,3 +235,75 @@ def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False):
 def save(path, flat, past_flow, **kw):
     with open(path, "wb") as f:
         Writer(f).obj(build_model(flat, past_flow, **kw))
+
+
+def build_model_legacy(flat, past_flow, replicas=2):
+    """A structurally different serialization of the same network, as an older / differently trained checkpoint could
+    look: plain nn.* classes on torch.FloatTensor, ALL parameters as views (offset + strides) into ONE flat storage (what
+    model:getParameters() leaves behind), convolution weights as 2-D Co x (Ci*9) views (SpatialConvolutionMM-style),
+    the bias of every other conv as a strided view, double-precision MulConstant-irrelevant extras, unknown fields,
+    serialized functions of all three tags, forward nodes in reverse order, and an nn.DataParallelTable with `replicas`
+    gModules (back2future.lua:114-116 takes the first)."""
+    g = build_model(flat, past_flow, cuda=False, cudnn=False, dpt=False)
+    flatv = np.asarray(flat, np.float32)
+    convs = []
+    seen = set()
+
+    def walk(o):
+        if id(o) in seen:
+            return
+        seen.add(id(o))
+        if isinstance(o, TorchObj):
+            if o.cls.endswith("SpatialConvolution"):
+                convs.append(o)
+            walk(o.fields)
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+    walk(g)
+    # one big storage: every distinct weight / bias array once (siamese clones keep sharing), biases interleaved with
+    # a gap so that their views are strided
+    pieces, where, total = [], {}, 3
+    for c in convs:
+        for name in ("weight", "bias"):
+            st = c.fields[name].storage
+            if id(st) not in where:
+                strided = name == "bias" and (len(where) % 4 == 1)
+                n = st.arr.size * (2 if strided else 1)
+                where[id(st)] = (total, strided)
+                pieces.append((total, st.arr, strided))
+                total += n + 5
+    big = np.full(total, np.float32(-777.0), np.float32)
+    for off, arr, strided in pieces:
+        if strided:
+            big[off:off + 2 * arr.size:2] = arr.ravel()
+        else:
+            big[off:off + arr.size] = arr.ravel()
+    store = Storage("torch.FloatStorage", big)
+    for i, c in enumerate(convs):
+        co, ci = int(c.fields["nOutputPlane"]), int(c.fields["nInputPlane"])
+        woff, _ = where[id(c.fields["weight"].storage)]
+        boff, bstr = where[id(c.fields["bias"].storage)]
+        c.fields["weight"] = Tensor("torch.FloatTensor", store, (co, ci * 9), offset=woff)           # 2-D view
+        c.fields["bias"] = Tensor("torch.FloatTensor", store, (co,), stride=[2 if bstr else 1], offset=boff)
+        del c.fields["gradWeight"], c.fields["gradBias"]
+        c.fields["finput"] = Tensor("torch.FloatTensor", Storage("torch.FloatStorage", np.zeros(0, np.float32)), ())
+        c.fields["_type"] = "torch.FloatTensor"
+        c.fields["accGradParameters"] = Function(6 if i % 3 == 0 else (7 if i % 3 == 1 else 8), {"n": i, "t": [1, 2, {"deep": True}]})
+        c.fields[7] = {"numeric key": 1.5}
+    g.fields["forwardnodes"] = list(reversed(g.fields["forwardnodes"]))
+    g.fields["modules"] = list(reversed(g.fields["modules"]))
+    g.fields["fg"] = TorchObj("graph.Graph", nodes=g.fields["forwardnodes"], edges=[], name="fg")
+    g.fields["type"] = Function(8)
+    second = TorchObj("nn.gModule", forwardnodes=[], modules=[], note="second replica: never read")
+    dpt = TorchObj("nn.DataParallelTable", modules=[g] + [second] * (replicas - 1), gpuAssignments=list(range(1, replicas + 1)),
+                   dimension=1, flattenedParams=[Tensor("torch.FloatTensor", store, (big.size,))], impl=Function(6))
+    return dpt
+
+
+def save_legacy(path, flat, past_flow, versioned=False, **kw):
+    with open(path, "wb") as f:
+        Writer(f, versioned=versioned).obj(build_model_legacy(flat, past_flow, **kw))

@@ -62,3 +62,31 @@ def test_errors(tmp_path):
     trunc.write_bytes(data[:len(data) // 3])
     with pytest.raises(_lib.B2FError):
         load_t7(str(trunc))
+
+
+@pytest.mark.parametrize("past_flow,versioned,replicas", [(False, False, 2), (True, True, 3), (True, False, 1)])
+def test_structurally_different_serialization(tmp_path, past_flow, versioned, replicas):
+    """tests/t7_writer.py:build_model_legacy: unversioned object headers, nn.* on FloatTensors, every parameter a view
+    (offset, 2-D weight, strided bias) into one flat storage, unknown fields, numeric table keys, serialized functions
+    of tags 6 / 7 / 8 (tag 6 carries no reference index), reversed forward nodes, a DataParallelTable with several
+    replicas."""
+    flat = W.random_init(13, past_flow, 1.0)
+    p = str(tmp_path / "legacy.t7")
+    t7_writer.save_legacy(p, flat, past_flow, versioned=versioned, replicas=replicas)
+    got, pf = load_t7(p)
+    assert pf == past_flow
+    np.testing.assert_array_equal(got, flat)
+    # one shared storage: the file is about the size of the parameters, not twice
+    assert os.path.getsize(p) < 1.6 * 4 * flat.size
+
+
+def test_function_tags_are_framed_independently(tmp_path):
+    """A table holding functions of all three tags followed by a marker: a reader that mis-frames one of them loses the
+    marker (tag 6 has NO reference index: ADVICE r1)."""
+    p = tmp_path / "f.t7"
+    with open(p, "wb") as f:
+        w = t7_writer.Writer(f)
+        w.obj({"a": t7_writer.Function(6, {"x": 1}), "b": t7_writer.Function(8, {"y": 2}), "c": t7_writer.Function(7),
+               "model": t7_writer.build_model(W.random_init(2, False, 1.0), False, cuda=False)})
+    got, pf = load_t7(str(p))
+    np.testing.assert_array_equal(got, W.random_init(2, False, 1.0))
