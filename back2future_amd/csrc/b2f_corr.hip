@@ -318,20 +318,30 @@ constexpr int TH2 = 16, TW2 = 16;
 constexpr int HH2 = TH2 + 2 * R, HW2 = TW2 + 2 * R;   // 24 x 24 halo
 constexpr int HP2 = 32;                              // LDS row pitch in pixels
 constexpr int NH2 = HH2 * HW2;                       // 576 halo pixels per map
-constexpr int NG = (2 * NH2 + 255) / 256;            // gather rounds: 5 (the last one half full)
+constexpr int PL2 = HH2 * HP2 + 4;                   // float4 per (map, k4) plane: 772 = 4 (mod 8), so that the lane pair
+                                                     // (pixel, k4 = 0 | 1) of the gather writes distinct LDS banks
 }  // namespace v2
 
-template <bool POW2>
-__global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaunch p)
+// NDIR = 2: 256 threads compute both directions of a tile (one gather pass covers both neighbour maps' halos).
+// NDIR = 1: 128 threads compute ONE direction (block parity): four independent blocks per CU instead of two, whose
+//           memory phases (gather, record stores -- HBM-bound) and compute phases overlap better.
+template <bool POW2, int NDIR>
+__global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const CorrLaunch p)
 {
     using namespace v2;
-    __shared__ __attribute__((aligned(16))) float4 nb[2][2][HH2 * HP2];   // [map][k4][pixel] 48 KB
-    __shared__ float4 samp_w[2 * NH2];                                     // 18 KB
-    __shared__ SampIdx samp_i[2 * NH2];                                    // 9 KB
+    constexpr int NTHR = 128 * NDIR;
+    constexpr int NPX = NDIR * NH2;                    // halo pixels this block gathers
+    constexpr int NG = (NPX + NTHR - 1) / NTHR;        // sampling-record rounds: 5 (the last one half full)
+    constexpr int NIT = NPX * 2 / NTHR;                // gather items (halo pixel, k4) per thread and chunk: 9
+    __shared__ __attribute__((aligned(16))) float4 nb[NDIR][2][PL2];      // [map][k4][pixel] 24 KB per map
+    __shared__ float4 samp_w[NPX];                                         // 9 KB per map
+    __shared__ SampIdx samp_i[NPX];                                        // 4.5 KB per map
 
     const int tid = threadIdx.x;
     const int tiles_x = (p.w + TW2 - 1) / TW2, tiles_y = (p.h + TH2 - 1) / TH2;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bdir = NDIR == 1 ? (bid & 1) : 0;        // NDIR = 1: direction of this block (0 fwd / future map, 1 bwd / past map)
+    if (NDIR == 1) bid >>= 1;
     const int tx_i = bid % tiles_x;
     bid /= tiles_x;
     const int ty_i = bid % tiles_y;
@@ -346,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaun
         float2 fl[NG];
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int i = min(tid + j * 256, 2 * NH2 - 1);
-            const int map = i / NH2, hp = i - map * NH2;
+            const int i = min(tid + j * NTHR, NPX - 1);
+            const int hp = i % NH2;
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int y = y0 - R + hy, x = x0 - R + hx;
             const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
@@ -356,9 +366,10 @@ __global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaun
         }
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int i = tid + j * 256;
-            if (i < 2 * NH2) {
-                const int map = i / NH2, hp = i - map * NH2;
+            const int i = tid + j * NTHR;
+            if (i < NPX) {
+                const int lmap = i / NH2, hp = i - lmap * NH2;
+                const int map = NDIR == 1 ? bdir : lmap;
                 const int hy = hp / HW2, hx = hp - hy * HW2;
                 const int y = y0 - R + hy, x = x0 - R + hx;
                 float4 wgt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaun
                     si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
                     wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
                 }
-                si.flags |= (map * (2 * HH2 * HP2) + hy * HP2 + hx) << 2;   // LDS slot of this halo pixel (k4 = 0 plane)
+                si.flags |= (lmap * (2 * PL2) + hy * HP2 + hx) << 2;   // LDS slot of this halo pixel (k4 = 0 plane)
                 samp_w[i] = wgt;
                 samp_i[i] = si;
             }
@@ -386,49 +397,51 @@ __global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaun
 #pragma unroll
     for (int i = 0; i < 81; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
-    const int pl = tid & 127, dir = tid >> 7;
+    const int pl = tid & 127, dir = NDIR == 1 ? bdir : (tid >> 7);
     const int tyr = pl >> 4, lx = pl & 15;
     const int py0 = y0 + 2 * tyr, px = x0 + lx;
     const bool v0 = py0 < p.h && px < p.w, v1 = py0 + 1 < p.h && px < p.w;
     const float *refp0 = ref + (size_t)(v0 ? (py0 * p.w + px) : 0) * p.pix_stride;
     const float *refp1 = ref + (size_t)(v1 ? ((py0 + 1) * p.w + px) : 0) * p.pix_stride;
     // neighbour (row f, qx) of the pair: LDS pixel (2 tyr + R + f, lx + R - qx)
-    const float4 *myn = &nb[dir][0][(2 * tyr + R) * HP2 + (lx + R)];
+    const float4 *myn = &nb[NDIR == 1 ? 0 : dir][0][(2 * tyr + R) * HP2 + (lx + R)];
 
     __syncthreads();
     const int nchunk = p.C >> 3;
     for (int ch = 0; ch < nchunk; ++ch) {
         const size_t coff = (size_t)ch * p.chunk_stride;
-        // ---- gather + blend the warped halo chunk into LDS (as the one-pixel kernel: one thread fetches both float4 of
-        // the chunk for its halo pixel, 8 loads in flight)
+        // ---- gather + blend the warped halo chunk into LDS.  Item = (halo pixel, k4): lanes 2i and 2i + 1 fetch the two
+        // 16-byte halves of the same pixel's chunk, so a wave's tap load covers 32 pixels x 32 contiguous bytes -- whole
+        // cache lines (8 - 10 per instruction instead of 16 - 20 when a lane fetched both halves 32 bytes apart from
+        // its neighbour's).  Three items = 12 loads in flight.
+        const int gk4 = tid & 1;
 #pragma unroll 1
-        for (int j = 0; j < NG; ++j) {
-            const int q = tid + j * 256;
-            if (q < 2 * NH2) {
-                const int map = q >= NH2;
-                const float4 wg = samp_w[q];
+        for (int j0 = 0; j0 < NIT; j0 += 3) {
+            float4 t[3][4], wg[3];
+            int slot[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int q = (tid >> 1) + (NTHR / 2) * (j0 + jj);
+                const int map = NDIR == 1 ? bdir : (q >= NH2);
+                wg[jj] = samp_w[q];
                 const SampIdx si = samp_i[q];
-                const float *src = nbr[map] + coff + si.idx;
+                const float *src = nbr[map] + coff + si.idx + 4 * gk4;
                 const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
-                float4 t[8];
+                slot[jj] = (si.flags >> 2) + gk4 * PL2;
+                t[jj][0] = *reinterpret_cast<const float4 *>(src);
+                t[jj][1] = *reinterpret_cast<const float4 *>(src + dx);
+                t[jj][2] = *reinterpret_cast<const float4 *>(src + dy);
+                t[jj][3] = *reinterpret_cast<const float4 *>(src + dy + dx);
+            }
 #pragma unroll
-                for (int k4 = 0; k4 < 2; ++k4) {
-                    t[k4 * 4 + 0] = *reinterpret_cast<const float4 *>(src + 4 * k4);
-                    t[k4 * 4 + 1] = *reinterpret_cast<const float4 *>(src + dx + 4 * k4);
-                    t[k4 * 4 + 2] = *reinterpret_cast<const float4 *>(src + dy + 4 * k4);
-                    t[k4 * 4 + 3] = *reinterpret_cast<const float4 *>(src + dy + dx + 4 * k4);
-                }
-                float4 *dst = &nb[0][0][0] + (si.flags >> 2);
-#pragma unroll
-                for (int k4 = 0; k4 < 2; ++k4) {
-                    const float4 tl = t[k4 * 4], tr = t[k4 * 4 + 1], bl = t[k4 * 4 + 2], br = t[k4 * 4 + 3];
-                    float4 v;
-                    v.x = fmaf(wg.w, br.x, fmaf(wg.z, bl.x, fmaf(wg.y, tr.x, wg.x * tl.x)));
-                    v.y = fmaf(wg.w, br.y, fmaf(wg.z, bl.y, fmaf(wg.y, tr.y, wg.x * tl.y)));
-                    v.z = fmaf(wg.w, br.z, fmaf(wg.z, bl.z, fmaf(wg.y, tr.z, wg.x * tl.z)));
-                    v.w = fmaf(wg.w, br.w, fmaf(wg.z, bl.w, fmaf(wg.y, tr.w, wg.x * tl.w)));
-                    dst[k4 * (HH2 * HP2)] = v;
-                }
+            for (int jj = 0; jj < 3; ++jj) {
+                const float4 w4 = wg[jj], tl = t[jj][0], tr = t[jj][1], bl = t[jj][2], br = t[jj][3];
+                float4 v;
+                v.x = fmaf(w4.w, br.x, fmaf(w4.z, bl.x, fmaf(w4.y, tr.x, w4.x * tl.x)));
+                v.y = fmaf(w4.w, br.y, fmaf(w4.z, bl.y, fmaf(w4.y, tr.y, w4.x * tl.y)));
+                v.z = fmaf(w4.w, br.z, fmaf(w4.z, bl.z, fmaf(w4.y, tr.z, w4.x * tl.z)));
+                v.w = fmaf(w4.w, br.w, fmaf(w4.z, bl.w, fmaf(w4.y, tr.w, w4.x * tl.w)));
+                (&nb[0][0][0])[slot[jj]] = v;
             }
         }
         const float4 ra[2] = {*reinterpret_cast<const float4 *>(refp0 + coff), *reinterpret_cast<const float4 *>(refp0 + coff + 4)};
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void warp_costvol_2px_kernel(const CorrLaun
             const int k4 = st / 10, f = st - 10 * k4 - 4;
             float4 cur[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) cur[j] = myn[k4 * (HH2 * HP2) + f * HP2 - (j - 4)];   // qx = j - 4
+            for (int j = 0; j < 9; ++j) cur[j] = myn[k4 * PL2 + f * HP2 - (j - 4)];   // qx = j - 4
             if (f <= 4) {
                 const float4 r = ra[k4];
                 const int qy = -f;
@@ -522,14 +535,19 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     const dim3 grid((unsigned)(tiles_x * tiles_y * p.B));
     const int t2x = (p.w + v2::TW2 - 1) / v2::TW2, t2y = (p.h + v2::TH2 - 1) / v2::TH2;
     const dim3 g2((unsigned)(t2x * t2y * p.B));
-    // Three instantiations of the same arithmetic (bit-identical results; p.variant 0 | 1 | 2 forces one):
-    //   2  two pixels per thread, 16 x 16 tiles: launches that fill the chip (>= 2 blocks per CU)
+    // Instantiations of the same arithmetic (bit-identical results; p.variant >= 0 forces one):
+    //   3  two pixels per thread, 16 x 16 tiles, one direction per 128-thread block (four blocks per CU): launches that
+    //      fill the chip -- measured at batch 16, level 3 / 4 / 5: 0.716 / 0.302 / 0.113 ms against 0.821 / 0.328 / 0.152
+    //   2  the same with both directions in one 256-thread block (two blocks per CU): 0.757 / 0.318 / 0.115
     //   1  one pixel per thread, all 24 gather loads of a chunk in flight: at most one round of two blocks per CU
     //   0  one pixel per thread, 8 x 16 tiles, three blocks per CU: in between
-    const int variant = p.variant >= 0 ? p.variant : (p.ablate ? 0 : g2.x >= 512 ? 2 : grid.x <= 512 ? 1 : 0);
+    const int variant = p.variant >= 0 ? p.variant : (p.ablate ? 0 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
     if (variant == 2) {
-        if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true>), g2, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((warp_costvol_2px_kernel<false>), g2, dim3(256), 0, s, p);
+        if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 2>), g2, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 2>), g2, dim3(256), 0, s, p);
+    } else if (variant == 3) {
+        if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 1>), dim3(2 * g2.x), dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 1>), dim3(2 * g2.x), dim3(128), 0, s, p);
     } else if (variant == 1) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_kernel<true, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_kernel<false, true>), grid, dim3(256), 0, s, p);

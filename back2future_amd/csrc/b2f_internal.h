@@ -100,7 +100,7 @@ struct CorrLaunch {
     int out_pix_stride;
     int B, C, h, w;
     int ablate = 0;                          // profiling only (option corr_ablate): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
-    int variant = -1;                        // -1 auto, 0 regular, 1 latency, 2 two-pixel instantiation (same arithmetic, same bits)
+    int variant = -1;                        // -1 auto, 0 regular, 1 latency, 2 two-pixel, 3 two-pixel one-direction-per-block instantiation (same bits)
 };
 #ifdef __HIPCC__
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one

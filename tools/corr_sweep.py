@@ -18,7 +18,7 @@ for it in range(n):
         h, w = int(rng.integers(60, 140)), int(rng.integers(100, 300))     # several tiles per block of the persistent kernel
     B = int(rng.integers(1, 4))
     k = float(rng.choice([0.3125, 0.625, 1.25, 2.5, 5.0]))
-    var = int(rng.integers(3))
+    var = int(rng.integers(4))
     m.set_option("corr_variant", var)      # 0 regular, 1 latency, 2 two-pixel instantiation
     ref = rng.standard_normal((B, C, h, w), dtype=np.float32)
     f3 = rng.standard_normal((B, C, h, w), dtype=np.float32)
