@@ -336,6 +336,7 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
     __shared__ __attribute__((aligned(16))) float4 nb[NDIR][2][PL2];      // [map][k4][pixel] 24 KB per map
     __shared__ float4 samp_w[NPX];                                         // 9 KB per map
     __shared__ SampIdx samp_i[NPX];                                        // 4.5 KB per map
+    __shared__ float pf_sink[NDIR * 192];                                  // landing zone of the L2 prefetch (never read)
 
     const int tid = threadIdx.x;
     const int tiles_x = (p.w + TW2 - 1) / TW2, tiles_y = (p.h + TH2 - 1) / TH2;
@@ -447,6 +448,29 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
         const float4 ra[2] = {*reinterpret_cast<const float4 *>(refp0 + coff), *reinterpret_cast<const float4 *>(refp0 + coff + 4)};
         const float4 rb[2] = {*reinterpret_cast<const float4 *>(refp1 + coff), *reinterpret_cast<const float4 *>(refp1 + coff + 4)};
         __syncthreads();
+        // ---- L2 prefetch of the NEXT chunk's source window, issued under this chunk's FMAs: the kernel is HBM-bound for
+        // 65 % of its time and the FMA phase holds the registers (162 accumulators), so the gather cannot be software-
+        // pipelined through VGPRs.  One LDS-DMA dword per cache line instead -- no registers, no wait: lane i of the first
+        // wave(s) touches line i % 7 of halo row i / 7 (7 lines cover a row's 24 x 32 bytes wherever it starts; row 24 = the
+        // bottom taps of the last row) at the address its sampling record points to; the data lands in pf_sink and is
+        // never read.  The gather of the next chunk then finds its lines in L2.
+        // (the reference pixels' loads are awaited first: vmcnt counts in order, and a wait placed after the DMA would
+        // drain it before the first FMA)
+        asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[1].x));
+        if (ch + 1 < nchunk && (tid >> 6) < NDIR) {
+            const int lmap = tid >> 6;
+            const int map = NDIR == 1 ? bdir : lmap;
+            const float *nbase = nbr[map] + coff + p.chunk_stride;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int i = (tid & 63) + 64 * it;
+                const int r = min(i / 7, HH2), sg = i - (i / 7) * 7;
+                const SampIdx si = samp_i[lmap * NH2 + min(r, HH2 - 1) * HW2 + min(4 * sg, HW2 - 1)];
+                const float *a = nbase + si.idx + (r == HH2 ? p.w * p.pix_stride : 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a,
+                                                 (__attribute__((address_space(3))) void *)(pf_sink + lmap * 192 + it * 64), 4, 0, 0);
+            }
+        }
         // ---- correlate: 20 steps = 2 k4 x 10 neighbour rows f = -4..5; row f is qy = -f of the upper pixel and
         // qy = 1 - f of the lower one (fwd volume: neighbour at (y - qy, x - qx), CostVolMulti.lua:76-87)
 #pragma unroll
