@@ -6,7 +6,7 @@ from back2future_amd import back2future, weights as W
 from oracle import oracle as O
 
 for which, past in (("hard", False), ("soft", True)):
-    for gain in (1.0, 2.0):
+    for gain in (1.0, 2.0, 3.0, 4.0):
         m = back2future.Model("random:%s:7:%s" % (which, gain))
         H, Wd = 384, 768
         r = np.random.default_rng(3)
