@@ -160,14 +160,22 @@ def cpu_baseline(H, W, seed, n=2):
     port = {"value": n / dt, "unit": "triplets/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "%d triplets at 3x%dx%d, pruned computeFlow graph of the Ours-Hard shape (the graph `value` runs), "
                       "oracle/b2f_oracle.c with OpenMP on all host cores, %.2f s" % (n, H, W, dt)}
-    T.compute_flow_graph(x[:1], params, False)                       # untimed: oneDNN builds its primitives per shape on first use
-    t0 = time.perf_counter()
-    flow, occ = T.compute_flow_graph(x, params, False)
-    dt = time.perf_counter() - t0
-    tch = {"value": n / dt, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "%d triplets at 3x%dx%d, same pruned graph in PyTorch-CPU %s (oneDNN, fp32, %d threads), %.2f s; "
-                     "max |flow - oracle| %.1e" % (n, H, W, torch.__version__, torch.get_num_threads(), dt,
-                                                   float(np.abs(flow - table[0]).max()))}
+    # PyTorch's intra-op pool does not scale to every core of a 2-socket host for this graph (128 threads measured 3x
+    # slower than 32): time a few pool sizes, report the best with the threads it used
+    best = None
+    ncpu = os.cpu_count() or 8
+    for nthr in sorted({min(ncpu, n) for n in (16, 32, 64, 128)}):
+        torch.set_num_threads(nthr)
+        T.compute_flow_graph(x[:1], params, False)                   # untimed: oneDNN builds its primitives per shape / pool size
+        t0 = time.perf_counter()
+        flow, occ = T.compute_flow_graph(x, params, False)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nthr, float(np.abs(flow - table[0]).max()))
+    dt, nthr, err = best
+    tch = {"value": n / dt, "unit": "triplets/s", "cores": nthr, "kind": "port",
+           "sample": "%d triplets at 3x%dx%d, same pruned graph in PyTorch-CPU %s (oneDNN, fp32), best of 16/32/64/128 intra-op "
+                     "threads: %d threads, %.2f s; max |flow - oracle| %.1e" % (n, H, W, torch.__version__, nthr, dt, err)}
     return port, tch
 
 
