@@ -309,6 +309,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Beside `value` (never as it): what computeFlow() of an Ours-Hard model really needs -- flow and est[3] = warped frame 1
+    # (back2future.lua:77,87 read est[1] and est[3] by position; for a Hard model the occlusion decoder of level 3 feeds
+    # only est[2], which computeFlow never looks at).  `value` keeps the occlusion decoder: SURVEY s8d's pruned graph.
+    def step_hard_exact():
+        model.forward_device(x.data_ptr(), B, H, W, flow.data_ptr(), None, est3.data_ptr(), unit_input=True, stream=stream)
+    for _ in range(3):
+        step_hard_exact()
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_hard_exact()
+    torch.cuda.synchronize()
+    hard_dt = time.perf_counter() - th0
+
     # per-kernel times: a second, UN-TIMED pass of the same steps, eager, with HIP events recorded by the library around
     # every launch on the launch stream (the event pairs cost ~2 % and graphs carry no events, so not in `value`)
     model.set_option("use_graph", 0)
@@ -345,6 +359,12 @@ def main():
         }
         if bcast:
             out["weights_broadcast"] = bcast
+        out["compute_flow_hard_exact"] = {
+            "what": "same workload without the level-3 occlusion decoder: everything computeFlow() of an Ours-Hard model reads "
+                    "(flow = est[1], masks from est[3] = warped frame 1); reported beside `value`, which keeps SURVEY s8d's pruned "
+                    "graph (occlusion decoder of level 3 included)",
+            "value": world * B * args.steps / hard_dt if world == 1 else None, "unit": "triplets/s (this rank)" if world > 1 else "triplets/s",
+            "rank0_value": B * args.steps / hard_dt, "ms_per_step": 1e3 * hard_dt / args.steps}
         if prof:
             conv_ms = sum(ms for k, (ms, n) in prof.items() if k.startswith("conv")) / args.steps
             conv_n = sum(n for k, (ms, n) in prof.items() if k.startswith("conv")) / args.steps
