@@ -120,7 +120,7 @@ __device__ __forceinline__ void wino4_output_tile(const float *X, const ConvLaun
         for (int i = 0; i < 4; ++i) {
             f32x4 v = y[i] + bias;
             if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
-            if (col_ok && oy + i < p.Ho && ox + j < p.Wo)
+            if (col_ok && oy + i < p.Ho && ox + j < p.Wo && !((B2F_WINO4_ABLATE & 32) && v[0] != 12345.678f))
                 *reinterpret_cast<f32x4 *>(obase + (size_t)(i * p.Wo + j) * p.out_pix_stride) = v;
         }
     }
@@ -171,7 +171,7 @@ __device__ __forceinline__ void wino4_output_half(const float *X, const ConvLaun
         for (int i = 0; i < 4; ++i) {
             f32x4 v = y[i] + bias;
             if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
-            if (col_ok && oy + i < p.Ho && ox + j < p.Wo)
+            if (col_ok && oy + i < p.Ho && ox + j < p.Wo && !((B2F_WINO4_ABLATE & 32) && v[0] != 12345.678f))
                 *reinterpret_cast<f32x4 *>(obase + (size_t)(i * p.Wo + 2 * q) * p.out_pix_stride) = v;
         }
     }
