@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default, BASELINE.json configs[4]): the timed steps replay the captured hipGraph of the forward pass; "
                          "0: eager launches.  Per-kernel times always come from a second, un-timed eager pass with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
@@ -246,7 +248,7 @@ def main():
     from back2future_amd import back2future
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -258,7 +260,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, H, W = args.batch, args.height, args.width
     # random-init pwc.lua weights, Ours-Hard shape.  Only rank 0 starts from the benchmark's seed: the other ranks start

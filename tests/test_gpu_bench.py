@@ -1,0 +1,45 @@
+"""GPU: bench.py itself -- the JSON contract of the single-GPU line and the N > 1 code path (two ranks sharing the one
+GPU of the test box over gloo: seeds diverge, the weight broadcast lands in the library's device buffer, the checksums
+agree, barrier / max-over-ranks timing)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--batch", "2", "--height", "128", "--width", "256", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-host-path"]
+
+
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_corrwarp"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["hip_graph"] is True and "workload" in d["config"]
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["bound"] == "mfma"          # a fraction of a roofline, never above 1
+    assert 0 < d["roofline_corrwarp"]["frac"] <= 1 and d["roofline_corrwarp"]["bound"] == "hbm"
+    assert d["value"] > 0 and d["outputs_finite"]
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
+    assert d["weights_broadcast"]["ranks"] == 2 and d["weights_broadcast"]["checksums_match"] is True
+    assert d["value"] > 0 and d["outputs_finite"]
