@@ -355,6 +355,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.nimg = nimg;
     L.nsplit = split ? 1 : 0;
     L.leaky = leaky;
+    L.tiles_per_block = c->s2_tiles_per_block;
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
@@ -789,6 +790,12 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
+    else if (!strcmp(key, "s2_tiles_per_block")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        c->s2_tiles_per_block = value;
+    }
     else if (!strcmp(key, "wino4_min_pixels") || !strcmp(key, "adaptive_kernels")) {
         // a different kernel mix: captured graphs hold the old one
         HIPCHK(hipSetDevice(c->device));
@@ -818,6 +825,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "host_graph") *value = c->host_graph;
     else if (k == "profile") *value = c->profile;
     else if (k == "profile_layers") *value = c->profile_layers;
+    else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
     else if (k == "corr_variant") *value = c->corr_variant;

@@ -67,39 +67,56 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
     const int n = lane & 31, half = lane >> 5;
 
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::TH - 1) / G::TH;
-    int bid = blockIdx.x;
-    const int tx_i = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty_i = bid % tiles_y;
-    const int img = bid / tiles_y;
+    const int ntiles_all = tiles_x * tiles_y * p.nimg;
+    // A block walks `tpb` consecutive tiles (p.tiles_per_block; 1 = one tile per block).  With more than one the
+    // (tile, chunk) pairs form ONE software pipeline: the loads of the next tile's first chunk are in flight under the
+    // last MFMAs and the output stores of the current tile -- a layer with two K chunks (16 -> 32, stride 2) then runs
+    // like a deep one instead of paying two memory round trips, a prologue and a store tail per 72 MFMAs.
+    const int tpb = p.tiles_per_block > 1 ? p.tiles_per_block : 1;
+    const int tile0 = blockIdx.x * tpb;
+    const int my_tiles = min(tpb, ntiles_all - tile0);
     const int nb = blockIdx.y;
-    const int ox0 = tx_i * TW, oy0 = ty_i * G::TH;
-    const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
+    int img = 0, ox0 = 0, oy0 = 0;               // tile of the item whose loads are issued next
+    int st_img = 0, st_ox0 = 0, st_oy0 = 0;       // tile of the item being computed / stored
 
-    // ---- per-thread staging coordinates for the A patch (fixed over chunks) ----
+    // ---- per-thread staging coordinates for the A patch (fixed over the chunks of a tile) ----
     unsigned a_off0[A_PER_THREAD], a_off1[A_PER_THREAD];   // byte offset inside the (image, chunk) plane, per K segment
     bool a_ok[A_PER_THREAD];    // false: halo outside the image / beyond the patch -> zero fill
     int a_lds[A_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
         const int idx = tid + i * NTHR;
-        const int pix = idx >> 1, h = idx & 1;
-        const int py = pix / PW, px = pix - py * PW;
-        const int gy = iy0 + py, gx = ix0 + px;
-        a_ok[i] = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const unsigned gp = a_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;   // unconditional load from a valid address, no branch
-        a_off0[i] = (gp * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
-        a_off1[i] = (gp * (unsigned)p.seg[1].pix_stride + (tid & 1) * 4) * 4u;
-        a_lds[i] = (idx < G::A_F4) ? (h * NPIX + pix) : -1;
+        a_lds[i] = (idx < G::A_F4) ? ((idx & 1) * NPIX + (idx >> 1)) : -1;
     }
+    __amdgpu_buffer_rsrc_t a_rsrc0, a_rsrc1;
+    auto enter_tile = [&](int t) {
+        int bid = t;
+        const int tx_i = bid % tiles_x;
+        bid /= tiles_x;
+        const int ty_i = bid % tiles_y;
+        img = bid / tiles_y;
+        ox0 = tx_i * TW; oy0 = ty_i * G::TH;
+        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i) {
+            const int idx = tid + i * NTHR;
+            const int pix = idx >> 1;
+            const int py = pix / PW, px = pix - py * PW;
+            const int gy = iy0 + py, gx = ix0 + px;
+            a_ok[i] = (idx < G::A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned gp = a_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;   // unconditional load from a valid address, no branch
+            a_off0[i] = (gp * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
+            a_off1[i] = (gp * (unsigned)p.seg[1].pix_stride + (tid & 1) * 4) * 4u;
+        }
+        // buffer loads: a scalar 128-bit resource (per K segment, based at this image), a scalar chunk offset and one
+        // 32-bit lane offset -- no per-load address arithmetic on the VALU
+        a_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
+        a_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
+    };
+    enter_tile(tile0);
+    st_img = img; st_ox0 = ox0; st_oy0 = oy0;
 
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
-    // buffer loads: a scalar 128-bit resource (per K segment, based at this image; the packed weights of this
-    // n-block), a scalar chunk offset and one 32-bit lane offset -- no per-load address arithmetic on the VALU
-    const __amdgpu_buffer_rsrc_t a_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t a_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.wpk + (size_t)nb * nchunks * B_F4 * 4), 0, 0x7fffffff, 0x00020000);
 
@@ -142,12 +159,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
 
     // ---- accumulators start at the bias (same order as y = b + sum in nn) ----
     f32x16 acc[NT];
+    float bias_v[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float bv = p.bias[nb * NTOT + t * 32 + n];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = bv;
-    }
+    for (int t = 0; t < NT; ++t) bias_v[t] = p.bias[nb * NTOT + t * 32 + n];
 
     // this lane's A pixel (M index m = lane & 31) inside the patch: wave w owns patch rows
     // w (TW == 32) or 2w, 2w+1 (TW == 16)
@@ -156,13 +170,27 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
     const int a_off = half * NPIX + (m_ty * S) * PW + m_tx * S;
     const int b_off = G::A_F4 + half * NTOT + n;
 
+    // item i = (tile i / nchunks, chunk i % nchunks); `lt`, `lc`: tile / chunk of the item whose loads are issued next
+    const int nitems = my_tiles * nchunks;
+    int lt = 0, lc = 0;
+    auto advance_load = [&]() {
+        if (++lc == nchunks) { lc = 0; ++lt; if (lt < my_tiles) enter_tile(tile0 + lt); }
+    };
     B2F_ISSUE_LOADS(0);
     B2F_WRITE_LDS(0);
     __syncthreads();
-    if (nchunks > 1) B2F_ISSUE_LOADS(1);
-    for (int c = 0; c < nchunks; ++c) {
-        const f32x4 *aptr = lds + (c & 1) * BUF_F4 + a_off;
-        const f32x4 *bptr = lds + (c & 1) * BUF_F4 + b_off;
+    advance_load();
+    if (nitems > 1) B2F_ISSUE_LOADS(lc);
+    int c = 0;
+    for (int it = 0; it < nitems; ++it) {
+        if (c == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = bias_v[t];
+        }
+        const f32x4 *aptr = lds + (it & 1) * BUF_F4 + a_off;
+        const f32x4 *bptr = lds + (it & 1) * BUF_F4 + b_off;
         f32x4 a = aptr[0], b[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) b[t] = bptr[t * 32];
@@ -189,36 +217,40 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_mfma(const ConvLaunch p)
 #pragma unroll
             for (int t = 0; t < NT; ++t) b[t] = bn[t];
         }
-        if (c + 1 < nchunks) {
-            // buffer (c+1)&1 was last read during chunk c-1; every wave passed the barrier that
-            // closed iteration c-1 after finishing those reads, so it is free to overwrite now
-            B2F_WRITE_LDS((c + 1) & 1);
+        if (++c == nchunks) {
+            c = 0;
+            // ---- epilogue of this tile: C/D layout col = lane & 31 (cout), row = (r&3) + 8*(r>>2) + 4*half ----
+            float *ob = p.out + (size_t)st_img * p.out_img_stride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = nb * NTOT + t * 32 + n;
+                if (co >= p.cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int ty = (TW == 32) ? wave : (2 * wave + (m >> 4));
+                    const int tx = (TW == 32) ? m : (m & 15);
+                    const int oy = st_oy0 + ty, ox = st_ox0 + tx;
+                    if (oy < p.Ho && ox < p.Wo) {
+                        float v = acc[t][r];
+                        if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+                        ob[(size_t)(co >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co & 7)] = v;
+                    }
+                }
+            }
+        }
+        if (it + 1 < nitems) {
+            // buffer (it+1)&1 was last read during item it-1; every wave passed the barrier that
+            // closed iteration it-1 after finishing those reads, so it is free to overwrite now
+            B2F_WRITE_LDS((it + 1) & 1);
+            if (c == 0) { st_img = img; st_ox0 = ox0; st_oy0 = oy0; }   // item it+1 opens the tile the staged loads belong to
             __syncthreads();
-            if (c + 2 < nchunks) B2F_ISSUE_LOADS(c + 2);
+            advance_load();
+            if (it + 2 < nitems) B2F_ISSUE_LOADS(lc);
         }
     }
 #undef B2F_ISSUE_LOADS
 #undef B2F_WRITE_LDS
-
-    // ---- epilogue: C/D layout col = lane & 31 (cout), row = (r&3) + 8*(r>>2) + 4*half ----
-    float *ob = p.out + (size_t)img * p.out_img_stride;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = nb * NTOT + t * 32 + n;
-        if (co >= p.cout) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int ty = (TW == 32) ? wave : (2 * wave + (m >> 4));
-            const int tx = (TW == 32) ? m : (m & 15);
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            if (oy < p.Ho && ox < p.Wo) {
-                float v = acc[t][r];
-                if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-                ob[(size_t)(co >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co & 7)] = v;
-            }
-        }
-    }
 }
 
 template <int S, int NT, int TW, int NW>
@@ -234,8 +266,19 @@ static hipError_t launch_t(const ConvLaunch &p, hipStream_t s)
         attr_done = true;
     }
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::TH - 1) / G::TH;
-    dim3 grid((unsigned)(tiles_x * tiles_y * p.nimg), (unsigned)p.nblk);
-    hipLaunchKernelGGL((conv3x3_mfma<S, NT, TW, NW>), grid, dim3(NW * 64), lds, s, p);
+    const int ntiles = tiles_x * tiles_y * p.nimg;
+    // tiles per block: shallow layers (few K chunks) of launches with many rounds of blocks chain tiles into one pipeline
+    ConvLaunch q = p;
+    int tpb = 1;
+    if (p.tiles_per_block > 0) tpb = p.tiles_per_block;
+    else {
+        const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+        const long blocks = (long)ntiles * p.nblk;
+        if (nchunks <= 8 && blocks >= 8 * 1024) tpb = nchunks <= 2 ? 8 : nchunks <= 4 ? 4 : 2;
+    }
+    q.tiles_per_block = tpb;
+    dim3 grid((unsigned)((ntiles + tpb - 1) / tpb), (unsigned)p.nblk);
+    hipLaunchKernelGGL((conv3x3_mfma<S, NT, TW, NW>), grid, dim3(NW * 64), lds, s, q);
     return hipGetLastError();
 }
 
