@@ -356,6 +356,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.nsplit = split ? 1 : 0;
     L.leaky = leaky;
     L.tiles_per_block = c->s2_tiles_per_block;
+    L.w4_persist = c->wino4_persistent;
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
@@ -683,6 +684,8 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->corr_variant = (int)env_int("B2F_CORR_LAT", c->corr_variant);
         c->corr_ablate = (int)env_int("B2F_CORR_ABLATE", c->corr_ablate);
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
+        c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
+        c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
         c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
         c->host_u8 = (int)env_int("B2F_HOST_U8", c->host_u8);
@@ -790,11 +793,11 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
-    else if (!strcmp(key, "s2_tiles_per_block")) {
+    else if (!strcmp(key, "s2_tiles_per_block") || !strcmp(key, "wino4_persistent")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
-        c->s2_tiles_per_block = value;
+        (key[0] == 's' ? c->s2_tiles_per_block : c->wino4_persistent) = value;
     }
     else if (!strcmp(key, "wino4_min_pixels") || !strcmp(key, "adaptive_kernels")) {
         // a different kernel mix: captured graphs hold the old one
@@ -826,6 +829,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "profile") *value = c->profile;
     else if (k == "profile_layers") *value = c->profile_layers;
     else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
+    else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
     else if (k == "corr_variant") *value = c->corr_variant;
@@ -1204,6 +1208,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.nt = nt; L.nblk = nblk; L.H = H; L.W = W; L.Ho = Ho; L.Wo = Wo; L.stride = stride; L.nimg = B; L.leaky = leaky;
     L.nsplit = op_split ? 1 : 0;
     L.nb0 = 0; L.trace = nullptr;
+    L.w4_persist = c->wino4_persistent;
     if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

@@ -53,6 +53,7 @@ struct ConvLaunch {
     long long *trace;   // profiling builds only (B2F_WINO_TRACE), nullptr otherwise
     int nb0;            // first n-block of this launch (Winograd kernel: a layer may be split over two launches)
     int nsplit;         // F(2x2) kernel: 1 = one block per 32-output N tile of the 64-wide packing (more, lighter blocks for small launches)
+    int w4_persist = 1;        // F(4x4) kernel: persistent blocks (one per CU) when the launch has at least two tiles per CU
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);

@@ -55,6 +55,8 @@ constexpr int U_F4 = 36 * 2 * 64;           // float4 of packed weights per (n-b
 constexpr int STAGE_BYTES = 16 * (2 * V_F4 + 2 * RAW_F4);
 constexpr int XCH_BYTES = 36 * 32 * 32 * 4;
 constexpr int LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
+constexpr int XQ_F4 = 36 * 8 * 64 / 4;                   // persistent kernel: exchange buffer of one tile row (8 tiles x 64 co x 36 xi)
+constexpr int P_LDS_BYTES = 16 * (2 * RAW_F4 + XQ_F4 + V_F4);   // [raw 0 | raw 1 | V 0 | gap | V 1] = 154 368
 __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2); }
 }  // namespace wino4
 
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 {
     using namespace wino4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VSTRIDE = V_F4;
     f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
     f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
 
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             }                                                                                       \
         }                                                                                           \
         if (t_write) {                                                                              \
-            f32x4 *v = Vb + (vbuf_) * V_F4 + t_dst;                                                 \
+            f32x4 *v = Vb + (vbuf_) * VSTRIDE + t_dst;                                                 \
             _Pragma("unroll") for (int b = 0; b < 6; ++b) v[64 * b] = vo[b];                        \
         }                                                                                           \
     } while (0)
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     long long *tr_buf = p.trace + (tr_on ? (tr_slot * 8 + wave) * 160 : 0);
 #endif
 #if B2F_WINO_TRACE
-    if (tr_on && lane == 0) { tr_buf[150] = t_start; tr_buf[151] = clock64(); }
+    if (tr_on && lane == 0) { tr_buf[150] = t_start; tr_buf[151] = clock64(); tr_buf[155] = wall_clock64(); }
 #endif
     // One chunk of the software pipeline as a macro with the phase PH_ of the B ring as a compile-time
     // parameter: the ring has 6 slots and runs 5 xi ahead (9 xi per chunk, so the slot pattern repeats every
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #undef W4_LDS_BARRIER
 #undef W4_DUMP_ACC
 #if B2F_WINO_TRACE
-    if (tr_on && lane == 0) tr_buf[153] = clock64();
+    if (tr_on && lane == 0) { tr_buf[153] = clock64(); tr_buf[156] = wall_clock64(); }
 #endif
     } else {
     // =====================================================================================================
@@ -617,10 +620,392 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     }
 #undef W4_LOAD_RAW
 #undef W4_WRITE_RAW
-#undef W4_T_READ
-#undef W4_T_FMA
-#undef W4_T_COLS
 #undef W4_LOAD_U
+}
+
+
+// =========================================================================================================
+// Persistent form of the two-N-tile kernel (round 2): one block per CU walks its tiles (virtual block index
+// v = blockIdx.x + k * gridDim.x, same logical order as the one-tile-per-block launch) and the software pipeline
+// of the K loop simply keeps running across tile boundaries -- the raw patch of the next tile's first three
+// chunks is loaded, staged and transformed by the last iterations of the current tile, so a tile has no prologue
+// (11 500 cycles of HBM latency + first transform per block in the one-tile form, which a single resident block
+// per CU cannot hide).  For that the output exchange must live beside the pipeline's buffers: LDS is laid out
+// [raw 0 | raw 1 | V 0 | gap | V 1] with |V 0 + gap| = |gap + V 1| = one TILE ROW (8 tiles x 64 channels x 36 xi,
+// 72 KB) of accumulators, the dead V buffer of the last chunk + the gap are the exchange buffer, and the output
+// stage runs in four passes (tile rows) in which ALL eight waves dump four accumulator registers per xi and then
+// transform: item = (tile, 4 channels, output column j), lanes ordered (tile column, j, channel half) so that a
+// wave's 16-byte stores cover 1 KB of contiguous memory (whole lines; the one-tile form writes 32-byte pieces).
+// Zero padding comes from the buffer loads' range check (offset >= num_records reads 0), so the staging state of
+// a tile is three byte offsets per thread and no LDS slot is ever "pre-zeroed".
+// =========================================================================================================
+__global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
+{
+    using namespace wino4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int VSTRIDE = XQ_F4;                               // V 1 starts one exchange buffer after V 0
+    f32x4 *Rb = reinterpret_cast<f32x4 *>(smem);                 // [2][RAW_F4]
+    f32x4 *Vb = Rb + 2 * RAW_F4;                                  // V 0 | gap | V 1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int g = wave & 3, n = wave >> 2;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int total = tiles_x * tiles_y * p.nimg * p.nblk;
+    const int G = gridDim.x;
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+
+    // ---- staging of the raw patch: thread tid < 408 = (patch row r6 < 6, patch column px < 34, k4 = tid & 1) stages the
+    // three pixels (r6 + 6 i, px), i = 0..2, of the 18 x 34 patch: ONE LDS slot and ONE byte offset per thread (item i
+    // adds an immediate to the slot and a scalar to the offset).  Nothing a thread holds depends on the tile: the tile
+    // enters through the base address of the buffer resource (scalar) and through three 64-bit lane masks (scalar: the
+    // lanes whose pixel lies inside the image; the others load at offset -16, which the range check of the buffer load
+    // turns into zeros -- the zero padding of the convolution)
+    constexpr int NSTG = 2 * 6 * PW;                             // 408 staging threads
+    const bool s_act = tid < NSTG;
+    int s_slot;
+    unsigned l_off;
+    {
+        const int pix = min(tid, NSTG - 1) >> 1;
+        const int r6 = pix / PW, px = pix - r6 * PW;
+        s_slot = (tid & 1) * RAW_P + r6 * RW + colpos(px);
+        l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
+    }
+    const int rowblk = 6 * p.W * p.seg[0].pix_stride * 4;        // bytes between the items of a thread
+    typedef unsigned long long u64;
+    u64 mk[3], mk_n[3];                                           // load side's tile / the block's next tile
+    __amdgpu_buffer_rsrc_t r_rsrc0, r_rsrc1;
+    int cur_nb, cur_img, cur_ox0, cur_oy0;                        // tile being computed / stored
+    int nxt_nb, nxt_img, nxt_ox0, nxt_oy0;                        // the block's next tile (decoded at the start of a tile)
+    bool has_next;
+    int lc = 0;                                                   // load side of the pipeline: next chunk of its tile
+#define W4P_DECODE(v_, nb_, img_, ox0_, oy0_)                                                       \
+    do {                                                                                            \
+        int bid__ = xcd_remap((v_), total);                                                         \
+        nb_ = bid__ % p.nblk + p.nb0;                                                               \
+        bid__ /= p.nblk;                                                                            \
+        ox0_ = (bid__ % tiles_x) * TW;                                                              \
+        bid__ /= tiles_x;                                                                           \
+        oy0_ = (bid__ % tiles_y) * TH;                                                              \
+        img_ = bid__ / tiles_y;                                                                     \
+    } while (0)
+    // lane masks of a tile, from the hardware lane id (no register held between tiles)
+#define W4P_MASKS(ox0_, oy0_, out_)                                                                 \
+    do {                                                                                            \
+        int z__ = 0;                                                                                \
+        asm volatile("" : "+v"(z__));                                                               \
+        const int ot__ = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z__)); \
+        const int pix__ = min(ot__, NSTG - 1) >> 1;                                                 \
+        const int r6__ = pix__ / PW, px__ = pix__ - r6__ * PW;                                      \
+        const int gx = (ox0_) - 1 + px__;                                                           \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
+            const int gy = (oy0_) - 1 + r6__ + 6 * i;                                               \
+            out_[i] = __builtin_amdgcn_ballot_w64(ot__ < NSTG && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W); \
+        }                                                                                           \
+    } while (0)
+    // buffer resources based at the patch origin (oy0 - 1, ox0 - 1) of a tile (may lie before the tensor: never dereferenced there)
+#define W4P_RSRC(img_, ox0_, oy0_)                                                                  \
+    do {                                                                                            \
+        const long long o__ = ((long long)((oy0_) - 1) * p.W + ((ox0_) - 1)) * p.seg[0].pix_stride; \
+        r_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[0].ptr) + ((long long)(img_) * p.seg[0].img_stride + o__), 0, 0x7fffffff, 0x00020000); \
+        r_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[1].ptr) + ((long long)(img_) * p.seg[1].img_stride + o__), 0, 0x7fffffff, 0x00020000); \
+    } while (0)
+    f32x4 sr[3];
+    // next item of the load stream -> sr; after a tile's last chunk the stream moves on to the block's next tile (and
+    // keeps re-reading the very last chunk when there is none: harmless).  Scalar work only at the switch.
+#define W4P_LOAD_STREAM()                                                                           \
+    do {                                                                                            \
+        const bool s1 = lc >= p.seg[0].nchunks;                                                     \
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
+        const int cc = s1 ? lc - p.seg[0].nchunks : lc;                                             \
+        const int so = (int)(cc * cstr * 4);                                                        \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
+            unsigned vo__;                                                                          \
+            asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(vo__) : "v"(l_off), "s"(mk[i]));         \
+            sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)vo__, so + i * rowblk, 0)); \
+        }                                                                                           \
+        if (++lc == nchunks) {                                                                      \
+            if (has_next) {                                                                         \
+                lc = 0;                                                                             \
+                mk[0] = mk_n[0]; mk[1] = mk_n[1]; mk[2] = mk_n[2];                                  \
+                W4P_RSRC(nxt_img, nxt_ox0, nxt_oy0);                                                \
+            } else {                                                                                \
+                lc = nchunks - 1;                                                                   \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+#define W4P_WRITE_RAW(buf_)                                                                         \
+    do {                                                                                            \
+        f32x4 *r = Rb + (buf_) * RAW_F4 + s_slot;                                                   \
+        if (s_act) { r[0] = sr[0]; r[6 * RW] = sr[1]; r[12 * RW] = sr[2]; }                         \
+    } while (0)
+
+    // ---- input transform role (as in conv3x3_wino4) ----
+    const int ta = wave < 6 ? wave : 5;
+    int r0, r1, r2, r3;
+    float c0, c1, c2, c3;
+    switch (ta) {
+    case 0: r0 = 0; r1 = 2; r2 = 4; r3 = 4; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; c3 = 1.f; break;
+    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
+    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; c3 = 1.f; break;
+    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
+    default: r0 = 1; r1 = 3; r2 = 5; r3 = 5; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    }
+    const int t_tile = lane & 31, t_k4 = lane >> 5;
+    const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
+    const int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
+    const float t_cf[4] = {c0, c1, c2, c3};
+    const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;
+    const bool t_write = wave < 6;
+    f32x4 R[6], d[3];
+
+    f32x16 acc[9];
+    const int a_off = (9 * g * 2 + half) * 32 + m;
+    const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
+    f32x4 av[3], bv[6];
+    __amdgpu_buffer_rsrc_t w_rsrc;
+#define W4P_LOAD_U(slot_, c_, x_)                                                                   \
+    bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((c_) * (U_F4 * 16) + (x_) * 2048), 0))
+
+#if B2F_WINO_TRACE
+    const int trp_slot = blockIdx.x == 40 ? 0 : blockIdx.x == 41 ? 1 : -1;
+    const bool trp_on = p.trace && trp_slot >= 0 && (wave == 0 || wave == 4) && lane == 0;
+    long long *trp_buf = p.trace + (trp_on ? (trp_slot * 2 + (wave >> 2)) * 160 : 0);
+    int trp_tile = 0;
+#define W4P_T(k_) do { if (trp_on && trp_tile < 12) trp_buf[trp_tile * 12 + (k_)] = clock64(); } while (0)
+#else
+#define W4P_T(k_) do {} while (0)
+#endif
+    // ---- first tile: prologue as in the one-tile kernel ----
+    if ((int)blockIdx.x >= total) return;
+    W4P_DECODE((int)blockIdx.x, cur_nb, cur_img, cur_ox0, cur_oy0);
+    W4P_MASKS(cur_ox0, cur_oy0, mk);
+    W4P_RSRC(cur_img, cur_ox0, cur_oy0);
+    has_next = false;                                                           // no switch inside the prologue (nchunks >= 4)
+    nxt_nb = cur_nb; nxt_img = cur_img; nxt_ox0 = cur_ox0; nxt_oy0 = cur_oy0;
+    mk_n[0] = mk[0]; mk_n[1] = mk[1]; mk_n[2] = mk[2];
+    int par = 0;                                                                // parity (V / raw buffer) of the tile's chunk 0
+    int v_cur = blockIdx.x;
+    {
+        f32x4 keep[3];
+        W4P_LOAD_STREAM();                       // chunk 0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep[i] = sr[i];
+        W4P_LOAD_STREAM();                       // chunk 1
+        if (s_act) {
+            f32x4 *r = Rb + s_slot;
+            r[0] = keep[0]; r[6 * RW] = keep[1]; r[12 * RW] = keep[2];
+        }
+        W4P_WRITE_RAW(1);
+        W4P_LOAD_STREAM();                       // chunk 2, stays in flight
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s); }
+    W4_T_COLS(0);
+    __syncthreads();
+
+    w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)cur_nb * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000);
+    W4P_LOAD_U(0, 0, 0); W4P_LOAD_U(1, 0, 1); W4P_LOAD_U(2, 0, 2); W4P_LOAD_U(3, 0, 3); W4P_LOAD_U(4, 0, 4);
+    for (;;) {
+        // ---- start of a tile: V[par] holds Tr(0), raw buffer par ^ 1 holds chunk 1, chunk 2 is in flight in sr, the
+        // first five B operands are in flight (issued under the last output pass of the previous tile) ----
+        W4P_T(0);
+#if B2F_WINO_TRACE
+        if (trp_on && trp_tile == 0) trp_buf[157] = wall_clock64();
+        if (trp_on && trp_tile == 11) { trp_buf[158] = wall_clock64(); trp_buf[159] = clock64(); }
+#endif
+        // the block's next tile: decoded and its lane masks computed here, where registers are plentiful (the
+        // accumulators are dead); the load side switches to it three chunks before this tile ends
+        has_next = v_cur + G < total;
+        if (has_next) {
+            W4P_DECODE(v_cur + G, nxt_nb, nxt_img, nxt_ox0, nxt_oy0);
+            W4P_MASKS(nxt_ox0, nxt_oy0, mk_n);
+        }
+        W4_T_READ(0, par ^ 1); W4_T_FMA(0);
+        W4_T_READ(1, par ^ 1); W4_T_FMA(1);
+        W4_T_READ(2, par ^ 1);
+        av[0] = Vb[par * VSTRIDE + a_off];
+        av[1] = Vb[par * VSTRIDE + a_off + 64];
+#pragma unroll
+        for (int x = 0; x < 9; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+#define W4P_CHUNK(PH_, c_, LAST_)                                                                        \
+    do {                                                                                            \
+        const int c = (c_);                                                                         \
+        const int pc = (par + c) & 1;                                                               \
+        const f32x4 *Vc = Vb + pc * VSTRIDE + a_off;                                                \
+        const f32x4 *Vn = Vb + (pc ^ 1) * VSTRIDE + a_off;                                          \
+        _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
+            if (x + 5 < 9) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c, x + 5);                           \
+            else if (!(LAST_)) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c + 1, x + 5 - 9);               \
+            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                               \
+            if (x == 6) av[8 % 3] = Vc[8 * 64];                                                     \
+            if (x == 7) av[0] = Vn[0];                                                              \
+            if (x == 8) av[1] = Vn[64];                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[(9 * (PH_) + x) % 6][j], acc[x], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if (x < 6) {                                                                            \
+                W4_T_FMA(x + 2);                                                                    \
+                if (x + 3 < 8) W4_T_READ(x + 3, pc ^ 1);                                            \
+            } else if (x == 6) {                                                                    \
+                W4_T_COLS(pc ^ 1);                                                                  \
+                W4P_WRITE_RAW(pc);                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                __syncthreads();                                                                    \
+                W4_T_READ(0, pc);                                                                   \
+                if (!(LAST_)) W4P_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
+            } else if (x == 7) {                                                                    \
+                W4_T_FMA(0); W4_T_READ(1, pc);                                                      \
+            } else {                                                                                \
+                W4_T_FMA(1); W4_T_READ(2, pc);                                                      \
+            }                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
+    } while (0)
+        W4P_T(1);
+        {
+            // the tile's last chunk is a separate instantiation that fetches no B operands of a following chunk (loads
+            // in flight into dead registers would hold up the output stage: the register allocator reuses them)
+            int c2 = 0;
+            for (; c2 + 2 < nchunks; c2 += 2) {
+                W4P_CHUNK(0, c2, false);
+                W4P_CHUNK(1, c2 + 1, false);
+            }
+            const bool even = c2 + 2 == nchunks;
+            if (even) W4P_CHUNK(0, c2, false);
+            if (even) W4P_CHUNK(1, c2 + 1, true);
+            if (!even) W4P_CHUNK(0, c2, true);
+        }
+#undef W4P_CHUNK
+        W4P_T(2);
+
+        // ---- output: four passes (tile rows) through the exchange buffer = dead V buffer + gap ----
+        const int pl = (par + nchunks - 1) & 1;                                 // V[pl] is dead, V[pl ^ 1] holds the next tile's Tr(0)
+        // output stage constants, derived here from an opaque copy of the lane id so that they are not hoisted out of
+        // the tile loop (the main loop has no registers to spare): dump addresses relative to the exchange buffer and
+        // the item of this thread
+        int oz = 0;
+        asm volatile("" : "+v"(oz));
+        const int olane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)oz));
+        const int om = olane & 31, ohalf = olane >> 5;
+        unsigned dump_rel[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t8 = e + 4 * ohalf;                                       // tile column inside the tile row
+            dump_rel[e] = 4u * (unsigned)((9 * g * 8 + t8) * 64 + ((n * 32 + om) ^ (t8 << 3)));
+        }
+        const int o_tx = olane >> 3, o_j = (olane >> 1) & 3, o_cq = 2 * wave + (olane & 1);
+        const int o_rel = o_tx * 64 + ((4 * o_cq) ^ (o_tx << 3));               // float index inside a xi plane (512 floats)
+        const float o_sg = (o_j & 1) ? -1.f : 1.f;
+        const float o_kq = o_j == 0 ? 1.f : o_j == 1 ? 2.f : o_j == 2 ? 4.f : 8.f;
+        const float o_k0 = o_j == 0 ? 1.f : 0.f, o_k3 = o_j == 3 ? 1.f : 0.f;
+        const int o_xe = o_j == 3 ? 5 * 512 : 0;                                // M5 for j = 3, M0 otherwise (weight 0 for j = 1, 2)
+        float *X = reinterpret_cast<float *>(Vb + pl * V_F4);
+        const unsigned xbase = static_cast<unsigned>(reinterpret_cast<size_t>(X));
+        float *ob = p.out + (size_t)cur_img * p.out_img_stride;
+        const int co0 = cur_nb * 64 + 4 * o_cq;
+        // bias of this wave's 8 channels through the scalar cache (a vector load here would wait, in order, behind the
+        // raw-patch loads of the next tile that are in flight)
+        // (constant address space: the weights are never written by this kernel, and only then does the compiler use s_load)
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat *bp = (cfloat *)(p.bias + cur_nb * 64 + 8 * wave);
+        float bb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bb[k] = bp[k];
+            asm volatile("" : "+s"(bb[k]));       // keeps the eight loads scalar (a select of loads becomes a vector load of a select)
+        }
+        const f32x4 bias = (olane & 1) ? f32x4{bb[4], bb[5], bb[6], bb[7]} : f32x4{bb[0], bb[1], bb[2], bb[3]};
+        const bool col_ok = co0 < p.cout;
+        const int ox = cur_ox0 + 4 * o_tx + o_j;
+        float *obase = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(cur_oy0 * p.Wo + ox) * p.out_pix_stride + (co0 & 7);
+        const float *xa = X + o_rel;
+#define W4P_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W4P_PASS(q_, EXTRA_)                                                                              \
+    do {                                                                                            \
+        asm volatile("; dump of tile row %0" ::"n"(q_));                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+            const unsigned da = xbase + dump_rel[e];                                                \
+            _Pragma("unroll") for (int x = 0; x < 8; x += 2)                                        \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"                   \
+                             :: "v"(da), "v"(acc[x][4 * (q_) + e]), "v"(acc[x + 1][4 * (q_) + e]), "n"(x * 8), "n"((x + 1) * 8) : "memory"); \
+            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(da), "v"(acc[8][4 * (q_) + e]), "n"(8 * 8 * 256) : "memory"); \
+        }                                                                                           \
+        W4P_T(3 + 3 * (q_));                                                                        \
+        W4P_LDS_BARRIER();                                                                          \
+        W4P_T(4 + 3 * (q_));                                                                        \
+        EXTRA_                                                                                      \
+        {                                                                                           \
+            const f32x4 sg4 = {o_sg, o_sg, o_sg, o_sg}, kq4 = {o_kq, o_kq, o_kq, o_kq};             \
+            const f32x4 k04 = {o_k0, o_k0, o_k0, o_k0}, k34 = {o_k3, o_k3, o_k3, o_k3};             \
+            const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f}; \
+            f32x4 T[6];                                                                             \
+            _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                         \
+                const float *xr6 = xa + (6 * a) * 512;                                              \
+                const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xr6 + 1 * 512), m2 = *reinterpret_cast<const f32x4 *>(xr6 + 2 * 512); \
+                const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xr6 + 3 * 512), m4 = *reinterpret_cast<const f32x4 *>(xr6 + 4 * 512); \
+                const f32x4 me = *reinterpret_cast<const f32x4 *>(xr6 + o_xe);                      \
+                const f32x4 e1 = W4_FMA(sg4, m2, m1), e2 = W4_FMA(sg4, m4, m3);                     \
+                /* the one-tile kernel's operations, element for element (batching must not change a bit): */ \
+                /* j=0 (M0 + s1) + s2, j=1 fma(2, d2, d1), j=2 fma(4, s2, s1), j=3 fma(8, d2, d1) + M5 */ \
+                T[a] = W4_FMA(k34, me, W4_FMA(kq4, e2, W4_FMA(k04, me, e1)));                       \
+            }                                                                                       \
+            const f32x4 s1 = T[1] + T[2], d1 = T[1] - T[2], s2 = T[3] + T[4], d2 = T[3] - T[4];     \
+            f32x4 y[4];                                                                             \
+            y[0] = T[0] + s1 + s2;                                                                  \
+            y[1] = W4_FMA(k2, d2, d1);                                                              \
+            y[2] = W4_FMA(k4, s2, s1);                                                              \
+            y[3] = W4_FMA(k8, d2, d1) + T[5];                                                       \
+            const int oy = cur_oy0 + 4 * (q_);                                                      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+                f32x4 v = y[i] + bias;                                                              \
+                if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);                            \
+                if (col_ok && oy + i < p.Ho && ox < p.Wo)                                           \
+                    *reinterpret_cast<f32x4 *>(obase + (size_t)((4 * (q_) + i) * p.Wo) * p.out_pix_stride) = v; \
+            }                                                                                       \
+        }                                                                                           \
+        W4P_LDS_BARRIER();                                                                          \
+        W4P_T(5 + 3 * (q_));                                                                        \
+    } while (0)
+        // the first B operands of the block's next tile are fetched under the last pass, when the accumulators are dead
+        // (without a next tile the loads re-read this tile's and are dropped)
+        // (the stream load the last chunk skipped: issued here, after the first dump, so that nothing is in flight
+        // when the dump claims registers; it has the rest of the output stage to land)
+        W4P_PASS(0, W4P_LOAD_STREAM(););
+        W4P_PASS(1, );
+        W4P_PASS(2, );
+        W4P_PASS(3,
+                 w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                     const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)nxt_nb * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000);
+                 W4P_LOAD_U(0, 0, 0); W4P_LOAD_U(1, 0, 1); W4P_LOAD_U(2, 0, 2); W4P_LOAD_U(3, 0, 3); W4P_LOAD_U(4, 0, 4););
+#undef W4P_PASS
+#undef W4P_LDS_BARRIER
+
+        // ---- next tile of this block: the one whose Tr(0) the last iteration left in V[pl ^ 1] ----
+        par = pl ^ 1;
+#if B2F_WINO_TRACE
+        ++trp_tile;
+#endif
+        if (!has_next) break;
+        v_cur += G;
+        cur_nb = nxt_nb; cur_img = nxt_img; cur_ox0 = nxt_ox0; cur_oy0 = nxt_oy0;
+    }
+#undef W4P_LOAD_U
+#undef W4P_WRITE_RAW
+#undef W4P_LOAD_STREAM
+#undef W4P_RSRC
+#undef W4P_MASKS
+#undef W4P_DECODE
 }
 
 template <int NTV>
@@ -640,7 +1025,9 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
 #if B2F_WINO_TRACE
     static long long *trace_dev = nullptr;
     static int traced = 0;
-    const bool do_trace = getenv("B2F_WINO_TRACE") && traced < 1 && NTV == 2 && p.seg[0].nchunks == 16 && p.nseg == 1 && p.H * p.W >= 256 * 480;
+    // B2F_WINO_TRACE=<total chunks of the layer to trace> (1 = the 16-chunk single-segment layer)
+    const int tr_want = getenv("B2F_WINO_TRACE") ? atoi(getenv("B2F_WINO_TRACE")) : 0;
+    const bool do_trace = tr_want > 0 && traced < 1 && NTV == 2 && p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0) == (tr_want == 1 ? 16 : tr_want) && p.H * p.W >= 256 * 480;
     if (do_trace) {
         if (!trace_dev) hipMalloc(&trace_dev, 32 * 160 * sizeof(long long));
         hipMemsetAsync(trace_dev, 0, 32 * 160 * sizeof(long long), s);
@@ -650,6 +1037,48 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
     dim3 grid((unsigned)(tiles * p.nimg * nblk));
+    if (NTV == 2 && p.w4_persist) {
+        // persistent form: one block per CU, worth it from two tiles per block
+        static int n_cu = 0;
+        static bool pattr_done = false;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+            n_cu &= ~7;                     // the XCD remap of the virtual block index needs a multiple of 8
+            if (n_cu < 8) n_cu = 8;
+        }
+        // w4_persist > 1 (tests): persistent form with exactly that many blocks, whatever the launch size
+        const int pgrid = p.w4_persist > 1 ? (p.w4_persist < (int)grid.x ? p.w4_persist : (int)grid.x) : n_cu;
+        const int nchunks_p = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+        if (nchunks_p >= 4 && (p.w4_persist > 1 || (int)grid.x >= 2 * n_cu)) {
+            if (!pattr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+                if (e != hipSuccess) return e;
+                pattr_done = true;
+            }
+            hipLaunchKernelGGL(conv3x3_wino4p, dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
+#if B2F_WINO_TRACE
+            if (do_trace) {
+                ++traced;
+                std::vector<long long> h(32 * 160);
+                hipStreamSynchronize(s);
+                hipMemcpy(h.data(), trace_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                for (int b = 0; b < 4; ++b) {
+                    const long long *t = h.data() + b * 160;
+                    fprintf(stderr, "shader clock over tiles 0..10: %.0f MHz\n", (double)(t[159] - t[0]) / ((double)(t[158] - t[157]) / 100.0));
+                    fprintf(stderr, "wino4p trace block-slot %d wave %d: per tile, cycles since the tile's first stamp: mini-prologue | loop | 4 x (dump, barrier wait, transform + barrier)\n", b >> 1, 4 * (b & 1));
+                    for (int k = 0; k < 12; ++k) {
+                        const long long *u = t + k * 12;
+                        fprintf(stderr, "  tile %2d  start +%7lld | %6lld %7lld |", k, k ? u[0] - t[(k - 1) * 12 + 0] : 0, u[1] - u[0], u[2] - u[1]);
+                        for (int q2 = 0; q2 < 4; ++q2) fprintf(stderr, "  %5lld %5lld %5lld", u[3 + 3 * q2] - u[2 + 3 * q2], u[4 + 3 * q2] - u[3 + 3 * q2], u[5 + 3 * q2] - u[4 + 3 * q2]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+#endif
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((conv3x3_wino4<NTV>), grid, dim3(512), LDS_BYTES, s, q);
 #if B2F_WINO_TRACE
     if (do_trace) {
@@ -664,6 +1093,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 for (int c = 0; c < 16; ++c)
                     fprintf(stderr, "  c=%2d  %7lld %7lld %7lld %7lld %7lld\n", c, t[c * 5] - t[0], t[c * 5 + 1] - t[0], t[c * 5 + 2] - t[0],
                             t[c * 5 + 3] - t[0], t[c * 5 + 4] - t[0]);
+                fprintf(stderr, "  shader clock loop start .. end: %.0f MHz\n", (double)(t[153] - t[151]) / ((double)(t[156] - t[155]) / 100.0));
                 fprintf(stderr, "  kernel start %lld, loop start %lld, loop end %lld, end %lld | epilogue stamps %lld %lld %lld %lld %lld\n", t[150] - t[0],
                         t[151] - t[0], t[152] - t[0], t[153] - t[0], t[140] - t[0], t[141] - t[0], t[142] - t[0], t[143] - t[0], t[144] - t[0]);
             }

@@ -78,6 +78,27 @@ def test_conv3x3_f2x2_one_n_tile_per_block(hard, ci, co, h, w):
     np.testing.assert_allclose(got, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("ci,co,h,w,blocks", [(128, 128, 40, 70, 3), (200, 128, 33, 65, 5), (32, 64, 17, 100, 2), (104, 192, 48, 33, 7),
+                                              (64, 100, 70, 31, 64), (40, 160, 16, 32, 2)])
+def test_conv3x3_wino4_persistent_blocks(hard, ci, co, h, w, blocks):
+    """The persistent form of the F(4x4) kernel (one block walks several tiles, the K pipeline runs across tile boundaries):
+    forced with a given number of blocks at test sizes -- odd and even chunk counts, ragged edges, one to many tiles per
+    block -- against the oracle and, bit for bit, against the one-tile-per-block kernel (the launcher picks between them by
+    launch size, and batching must not change a bit)."""
+    r = _rng(ci * 7 + co + blocks)
+    x = r.standard_normal((3, ci, h, w), dtype=np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = r.standard_normal(co, dtype=np.float32)
+    with hard.options(wino4_persistent=0):
+        one_tile = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino4_persistent=blocks):   # values > 1: exactly that many persistent blocks
+        got = ops.conv3x3(hard, x, wt, b, 1, True)
+    exp = O.conv3x3(x, wt, b, 1, True)
+    np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1.5e-4)
+    assert np.abs(got - exp).mean() < 5e-6
+    assert np.array_equal(got, one_tile)
+
+
 def test_conv3x3_transpose_detecting(hard):
     """asymmetric single-tap kernels: catches swapped rows/cols, taps or channels."""
     x = np.arange(2 * 8 * 6 * 10, dtype=np.float32).reshape(2, 8, 6, 10) / 100
