@@ -639,6 +639,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 // Zero padding comes from the buffer loads' range check (offset >= num_records reads 0), so the staging state of
 // a tile is three byte offsets per thread and no LDS slot is ever "pre-zeroed".
 // =========================================================================================================
+template <int NTV>
 __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 {
     using namespace wino4;
@@ -761,8 +762,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     const float t_cf[4] = {c0, c1, c2, c3};
     const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;
     const bool t_write = wave < 6;
-    f32x4 R[6], d[3];
+    f32x4 R[6], d[NTV == 1 ? 6 : 3];
 
+    if constexpr (NTV == 2) {
     f32x16 acc[9];
     const int a_off = (9 * g * 2 + half) * 32 + m;
     const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
@@ -1000,6 +1002,175 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         v_cur += G;
         cur_nb = nxt_nb; cur_img = nxt_img; cur_ox0 = nxt_ox0; cur_oy0 = nxt_oy0;
     }
+    } else {
+    // =====================================================================================================
+    // Single N tile (the last 32 channels of a layer whose cout is 32 mod 64, nblk == 1): the 36 xi split over all
+    // eight waves as in conv3x3_wino4<1> (wave (g, n): xi = 9g + 5n + x, x = 0..4), simple pipeline (B operands a
+    // whole chunk ahead, the raw patch two chunks ahead, one barrier per chunk), persistent over tiles: the stream of
+    // raw chunks and the B operands run on into the next tile (same weights for every tile), the output stage takes
+    // two passes (two tile rows = 16 tiles x 32 channels x 36 xi = 72 KB each) through the dead V buffer + gap.
+    // Arithmetic of the output transform = wino4_output_half's, element for element.
+    // =====================================================================================================
+    f32x16 acc[5];
+    int xo[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) xo[x] = min(9 * g + 5 * n + x, 35);
+    const int a_lane = half * 32 + m;                       // V[xi][k4 = half][tile m] = xi * 64 + a_lane (float4)
+    const unsigned b_lane = (half * 64 + m) * 16u;          // bytes: U[xi][k4 = half][co m] = xi * 2048 + b_lane
+    f32x4 av[5], bc[5], bn[5];
+    if ((int)blockIdx.x >= total) return;
+    W4P_DECODE((int)blockIdx.x, cur_nb, cur_img, cur_ox0, cur_oy0);
+    W4P_MASKS(cur_ox0, cur_oy0, mk);
+    W4P_RSRC(cur_img, cur_ox0, cur_oy0);
+    has_next = false;
+    nxt_nb = cur_nb; nxt_img = cur_img; nxt_ox0 = cur_ox0; nxt_oy0 = cur_oy0;
+    mk_n[0] = mk[0]; mk_n[1] = mk[1]; mk_n[2] = mk[2];
+    int par = 0;
+    int v_cur = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)cur_nb * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000);
+#define W4Q_LOAD_U(dst_, c_)                                                                        \
+    _Pragma("unroll") for (int x = 0; x < 5; ++x)                                                   \
+        dst_[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_lane, (int)((c_) * (U_F4 * 16) + xo[x] * 2048), 0))
+    {
+        f32x4 keep[3];
+        W4P_LOAD_STREAM();                       // chunk 0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) keep[i] = sr[i];
+        W4P_LOAD_STREAM();                       // chunk 1
+        W4Q_LOAD_U(bc, 0);
+        if (s_act) {
+            f32x4 *r = Rb + s_slot;
+            r[0] = keep[0]; r[6 * RW] = keep[1]; r[12 * RW] = keep[2];
+        }
+        W4P_WRITE_RAW(1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2); }
+    W4_T_COLS(0);
+    __syncthreads();
+    for (;;) {
+        has_next = v_cur + G < total;
+        if (has_next) {
+            W4P_DECODE(v_cur + G, nxt_nb, nxt_img, nxt_ox0, nxt_oy0);
+            W4P_MASKS(nxt_ox0, nxt_oy0, mk_n);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            const int pc = (par + c) & 1;
+            const int cn = c + 1 < nchunks ? c + 1 : 0;          // after the last chunk: chunk 0 of the next tile (same weights)
+            W4Q_LOAD_U(bn, cn);
+            W4P_LOAD_STREAM();                                   // two chunks ahead (runs on into the next tile)
+            const f32x4 *Vc = Vb + pc * VSTRIDE + a_lane;
+#pragma unroll
+            for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 3); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x < 4 || n == 0)       // the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch)
+                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (x < 4) { W4_T_FMA_D(2 * x, 0); W4_T_FMA_D(2 * x + 1, 3); }
+                else { W4_T_COLS(pc ^ 1); W4P_WRITE_RAW(pc); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 5; ++x) bc[x] = bn[x];
+        }
+        // ---- output: two passes (tile rows 2h, 2h + 1) through the dead V buffer + gap ----
+        const int pl = (par + nchunks - 1) & 1;
+        float *X = reinterpret_cast<float *>(Vb + pl * V_F4);
+        const unsigned xbase = static_cast<unsigned>(reinterpret_cast<size_t>(X));
+        int oz = 0;
+        asm volatile("" : "+v"(oz));
+        const int olane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)oz));
+        const int om = olane & 31, ohalf = olane >> 5;
+        unsigned dump_rel[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t16 = e + 4 * ohalf;                                      // + 8 for the second tile row of the pass
+            dump_rel[e] = 4u * (unsigned)(t16 * 32 + (om ^ (((t16 >> 1) & 3) << 3)));
+        }
+        const int o_tx = olane >> 3, o_j = (olane >> 1) & 3, o_cq = 2 * (wave >> 1) + (olane & 1);
+        const int o_rel = ((wave & 1) * 8 + o_tx) * 32 + ((4 * o_cq) ^ (((o_tx >> 1) & 3) << 3));
+        const float o_sg = (o_j & 1) ? -1.f : 1.f;
+        const float o_kq = o_j == 0 ? 1.f : o_j == 1 ? 2.f : o_j == 2 ? 4.f : 8.f;
+        const float o_ke = (o_j == 0 || o_j == 3) ? 1.f : 0.f;
+        const int o_xe = (o_j & 1) ? 5 * 512 : 0;                                // M5 for the odd columns, M0 for the even ones
+        float *ob = p.out + (size_t)cur_img * p.out_img_stride;
+        const int co0 = cur_nb * 64 + 4 * o_cq;
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat *bp = (cfloat *)(p.bias + cur_nb * 64 + 8 * (wave >> 1));
+        float bb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bb[k] = bp[k];
+            asm volatile("" : "+s"(bb[k]));
+        }
+        const f32x4 bias = (olane & 1) ? f32x4{bb[4], bb[5], bb[6], bb[7]} : f32x4{bb[0], bb[1], bb[2], bb[3]};
+        const bool col_ok = co0 < p.cout;
+        const int ox = cur_ox0 + 4 * o_tx + o_j;
+        float *obase = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((cur_oy0 + 4 * (wave & 1)) * p.Wo + ox) * p.out_pix_stride + (co0 & 7);
+        const float *xa = X + o_rel;
+#define W4Q_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W4Q_PASS(h_)                                                                                \
+    do {                                                                                            \
+        _Pragma("unroll") for (int x = 0; x < 5; ++x)                                               \
+            if (x < 4 || n == 0) {                                                                  \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+                    const unsigned da = xbase + dump_rel[e] + (unsigned)xo[x] * 2048u;              \
+                    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:4"                 \
+                                 :: "v"(da), "v"(acc[x][8 * (h_) + e]), "v"(acc[x][8 * (h_) + 4 + e]) : "memory"); \
+                }                                                                                   \
+            }                                                                                       \
+        W4Q_LDS_BARRIER();                                                                          \
+        {                                                                                           \
+            const f32x4 sg4 = {o_sg, o_sg, o_sg, o_sg}, kq4 = {o_kq, o_kq, o_kq, o_kq}, ke4 = {o_ke, o_ke, o_ke, o_ke}; \
+            const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f}; \
+            f32x4 T[6];                                                                             \
+            _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                         \
+                const float *xr6 = xa + (6 * a) * 512;                                              \
+                const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xr6 + 1 * 512), m2 = *reinterpret_cast<const f32x4 *>(xr6 + 2 * 512); \
+                const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xr6 + 3 * 512), m4 = *reinterpret_cast<const f32x4 *>(xr6 + 4 * 512); \
+                const f32x4 me = *reinterpret_cast<const f32x4 *>(xr6 + o_xe);                      \
+                const f32x4 e1 = W4_FMA(sg4, m2, m1), e2 = W4_FMA(sg4, m4, m3);                     \
+                T[a] = W4_FMA(ke4, me, W4_FMA(kq4, e2, e1));                                        \
+            }                                                                                       \
+            const f32x4 s1 = T[1] + T[2], d1 = T[1] - T[2], s2 = T[3] + T[4], d2 = T[3] - T[4];     \
+            f32x4 y[4];                                                                             \
+            y[0] = T[0] + s1 + s2;                                                                  \
+            y[1] = W4_FMA(k2, d2, d1);                                                              \
+            y[2] = W4_FMA(k4, s2, s1);                                                              \
+            y[3] = W4_FMA(k8, d2, d1) + T[5];                                                       \
+            const int oy = cur_oy0 + 8 * (h_) + 4 * (wave & 1);                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+                f32x4 v = y[i] + bias;                                                              \
+                if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);                            \
+                if (col_ok && oy + i < p.Ho && ox < p.Wo)                                           \
+                    *reinterpret_cast<f32x4 *>(obase + (size_t)((8 * (h_) + i) * p.Wo) * p.out_pix_stride) = v; \
+            }                                                                                       \
+        }                                                                                           \
+        W4Q_LDS_BARRIER();                                                                          \
+    } while (0)
+        W4Q_PASS(0);
+        W4Q_PASS(1);
+#undef W4Q_PASS
+#undef W4Q_LDS_BARRIER
+        par = pl ^ 1;
+        if (!has_next) break;
+        v_cur += G;
+        cur_nb = nxt_nb; cur_img = nxt_img; cur_ox0 = nxt_ox0; cur_oy0 = nxt_oy0;
+    }
+#undef W4Q_LOAD_U
+    }
 #undef W4P_LOAD_U
 #undef W4P_WRITE_RAW
 #undef W4P_LOAD_STREAM
@@ -1037,7 +1208,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
     dim3 grid((unsigned)(tiles * p.nimg * nblk));
-    if (NTV == 2 && p.w4_persist) {
+    if (p.w4_persist) {
         // persistent form: one block per CU, worth it from two tiles per block
         static int n_cu = 0;
         static bool pattr_done = false;
@@ -1052,11 +1223,11 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
         const int nchunks_p = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
         if (nchunks_p >= 4 && (p.w4_persist > 1 || (int)grid.x >= 2 * n_cu)) {
             if (!pattr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
                 if (e != hipSuccess) return e;
                 pattr_done = true;
             }
-            hipLaunchKernelGGL(conv3x3_wino4p, dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
+            hipLaunchKernelGGL((conv3x3_wino4p<NTV>), dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
 #if B2F_WINO_TRACE
             if (do_trace) {
                 ++traced;

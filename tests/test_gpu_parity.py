@@ -79,7 +79,7 @@ def test_conv3x3_f2x2_one_n_tile_per_block(hard, ci, co, h, w):
 
 
 @pytest.mark.parametrize("ci,co,h,w,blocks", [(128, 128, 40, 70, 3), (200, 128, 33, 65, 5), (32, 64, 17, 100, 2), (104, 192, 48, 33, 7),
-                                              (64, 100, 70, 31, 64), (40, 160, 16, 32, 2)])
+                                              (64, 100, 70, 31, 64), (40, 160, 16, 32, 2), (32, 32, 49, 35, 5), (128, 96, 36, 83, 17), (64, 32, 20, 70, 3)])
 def test_conv3x3_wino4_persistent_blocks(hard, ci, co, h, w, blocks):
     """The persistent form of the F(4x4) kernel (one block walks several tiles, the K pipeline runs across tile boundaries):
     forced with a given number of blocks at test sizes -- odd and even chunk counts, ragged edges, one to many tiles per

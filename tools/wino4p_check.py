@@ -12,7 +12,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 worst_o, worst_k = 0.0, 0.0
 for it in range(n):
     ci = int(rng.choice([8, 16, 24, 32, 40, 64, 96, 104, 128, 200]))
-    co = int(rng.choice([64, 68, 96, 100, 128, 160, 192]))
+    co = int(rng.choice([32, 64, 68, 96, 100, 128, 160, 192]))
     h, w = int(rng.integers(1, 70)), int(rng.integers(1, 100))
     B = int(rng.integers(1, 4))
     x = rng.standard_normal((B, ci, h, w), dtype=np.float32)
