@@ -758,16 +758,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     }
     const int t_tile = lane & 31, t_k4 = lane >> 5;
     const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
-    const int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
+    int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
     const float t_cf[4] = {c0, c1, c2, c3};
-    const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;
+    int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;
     const bool t_write = wave < 6;
     f32x4 R[6], d[NTV == 1 ? 6 : 3];
 
     if constexpr (NTV == 2) {
     f32x16 acc[9];
-    const int a_off = (9 * g * 2 + half) * 32 + m;
-    const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
+    int a_off = (9 * g * 2 + half) * 32 + m;
+    unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
     f32x4 av[3], bv[6];
     __amdgpu_buffer_rsrc_t w_rsrc;
 #define W4P_LOAD_U(slot_, c_, x_)                                                                   \
@@ -828,6 +828,22 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         if (has_next) {
             W4P_DECODE(v_cur + G, nxt_nb, nxt_img, nxt_ox0, nxt_oy0);
             W4P_MASKS(nxt_ox0, nxt_oy0, mk_n);
+        }
+        {   // the per-lane constants of the main loop, recomputed from the hardware lane id: held across the output
+            // stage they were spilled, and a spill reload here waits (vmcnt counts in order) for the output stores
+            int lz = 0;
+            asm volatile("" : "+v"(lz));
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)lz));
+            const int lm = ln & 31, lh = ln >> 5, ltid = wave * 64 + ln;
+            const int tb = lh * RAW_P + (4 * (lm >> 3)) * RW + (lm & 7);
+            t_row[0] = tb + r0 * RW; t_row[1] = tb + r1 * RW; t_row[2] = tb + r2 * RW; t_row[3] = tb + r3 * RW;
+            t_dst = (ta * 6 * 2 + lh) * 32 + lm;
+            a_off = (9 * g * 2 + lh) * 32 + lm;
+            b_off = ((9 * g * 2 + lh) * 64 + n * 32 + lm) * 16u;
+            const int pix = min(ltid, NSTG - 1) >> 1;
+            const int r6 = pix / PW, px = pix - r6 * PW;
+            s_slot = (ltid & 1) * RAW_P + r6 * RW + colpos(px);
+            l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (ltid & 1) * 4) * 4u;
         }
         W4_T_READ(0, par ^ 1); W4_T_FMA(0);
         W4_T_READ(1, par ^ 1); W4_T_FMA(1);
