@@ -548,6 +548,298 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
     store_px(acc1, v1, py0 + 1);
 }
 
+
+// ======================================================================================================
+// Window-staged variant (round 2, variant 4): the gather of the two-pixel kernel issues four 16-byte tap loads per
+// halo pixel and chunk half through the vector memory pipe -- 9x the bytes of the source window they come from -- in
+// three dependent rounds per chunk (the 162 accumulators leave registers for 12 loads in flight).  Here the UNWARPED
+// source window of the tile's halo (bounding box of the clamped tap coordinates, at most 32 x 32 pixels) is brought
+// into LDS by LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous) and the bilinear blend reads its four taps
+// from LDS.  Work is cut into half chunks (4 channels): per half chunk  [wait DMA | barrier | blend window -> warped
+// halo plane | barrier | issue the DMA of the NEXT half chunk | 2 x 81 x 4 FMAs], so the memory round trip of the next
+// window runs under the FMAs of this one, and one halo plane + one 16-byte-per-pixel window + compact sampling records
+// (tap coordinates, wx, wy) fit four blocks per CU (37 KB).  One direction per 128-thread block, 16 x 16 tiles, two
+// pixels per thread, the same arithmetic in the same order as the other variants: identical results.  A tile whose
+// flow spreads the taps over more than 32 x 32 pixels gathers from memory instead (block-uniform fallback).
+namespace v4 {
+constexpr int WP = 32, WROWS = 32;                   // window pitch / rows in pixels
+}  // namespace v4
+
+// Profiling only (results are wrong): -DB2F_WIN_ABLATE=bits, 1 no DMA, 2 no blend, 4 no FMA phase, 8 no record stores
+#ifndef B2F_WIN_ABLATE
+#define B2F_WIN_ABLATE 0
+#endif
+template <bool POW2>
+__global__ __launch_bounds__(128, 2) void warp_costvol_win_kernel(const CorrLaunch p)
+{
+    using namespace v2;
+    using namespace v4;
+    constexpr int NTHR = 128;
+    constexpr int NG = (NH2 + NTHR - 1) / NTHR;        // 5 halo pixels per thread (the last round half full)
+    __shared__ __attribute__((aligned(16))) float4 nb[PL2];              // warped halo, one 4-channel plane
+    __shared__ __attribute__((aligned(16))) float4 win[WROWS * WP];      // source window, 4 channels per pixel
+    __shared__ int samp_i[NH2];                                           // xl | yt << 12 | flags << 24 | valid << 26
+    __shared__ float2 samp_w[NH2];                                        // wx, wy
+    __shared__ int samp_f[NH2];                                           // window index | dx << 10 | dy << 11 | halo slot << 12 | valid << 22
+    __shared__ int bbox[4];
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.w + TW2 - 1) / TW2, tiles_y = (p.h + TH2 - 1) / TH2;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int dir = bid & 1;                            // 0 fwd / future map, 1 bwd / past map
+    bid >>= 1;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx_i * TW2, y0 = ty_i * TH2;
+
+    const float *ref = p.ref + (size_t)b * p.img_stride;
+    const float *nbr = (dir == 0 ? p.nbr_fut : p.nbr_past) + (size_t)b * p.img_stride;
+
+    if (tid < 2) bbox[tid] = 0x7fffffff;
+    else if (tid < 4) bbox[tid] = -1;
+    // ---- sampling records of the halo (once per block) and the bounding box of their taps
+    {
+        float2 fl[NG];
+        size_t fo[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int hp = min(tid + j * NTHR, NH2 - 1);
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
+            fl[j] = make_float2(0.f, 0.f);
+            fo[j] = ((size_t)b * p.h * p.w + (in ? (size_t)y * p.w + x : 0)) * 2;
+        }
+        if (p.flow) {                                   // one uniform branch around all five loads: they are in flight together
+#pragma unroll
+            for (int j = 0; j < NG; ++j) fl[j] = *reinterpret_cast<const float2 *>(p.flow + fo[j]);
+        }
+        __syncthreads();                                // bbox initialised
+        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int hp = tid + j * NTHR;
+            if (hp < NH2) {
+                const int hy = hp / HW2, hx = hp - hy * HW2;
+                const int y = y0 - R + hy, x = x0 - R + hx;
+                int rec = 0;
+                float2 wxy = make_float2(0.f, 0.f);
+                if (y >= 0 && y < p.h && x >= 0 && x < p.w) {
+                    const float k = dir == 0 ? p.k : -p.k;   // nn.MulConstant(20*(f-ref)/2^(l-2)), pwc.lua:404
+                    const float u = fl[j].x * k, v = fl[j].y * k;
+                    int xl, yt;
+                    float wx, wy;
+                    top_left(u + (float)x, p.w, xl, wx);
+                    top_left(v + (float)y, p.h, yt, wy);
+                    const int fx = (xl + 1 <= p.w - 1) ? 1 : 0, fy = (yt + 1 <= p.h - 1) ? 1 : 0;
+                    rec = xl | yt << 12 | fx << 24 | fy << 25 | 1 << 26;
+                    wxy = make_float2(wx, wy);
+                    bx0 = min(bx0, xl); by0 = min(by0, yt);
+                    bx1 = max(bx1, xl + fx); by1 = max(by1, yt + fy);
+                }
+                samp_i[hp] = rec;
+                samp_w[hp] = wxy;
+            }
+        }
+        atomicMin(&bbox[0], bx0); atomicMin(&bbox[1], by0);
+        atomicMax(&bbox[2], bx1); atomicMax(&bbox[3], by1);
+    }
+
+    float acc0[81], acc1[81];   // upper / lower pixel of the pair
+#pragma unroll
+    for (int i = 0; i < 81; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int tyr = tid >> 4, lx = tid & 15;
+    const int py0 = y0 + 2 * tyr, px = x0 + lx;
+    const bool v0 = py0 < p.h && px < p.w, v1 = py0 + 1 < p.h && px < p.w;
+    const float *refp0 = ref + (size_t)(v0 ? (py0 * p.w + px) : 0) * p.pix_stride;
+    const float *refp1 = ref + (size_t)(v1 ? ((py0 + 1) * p.w + px) : 0) * p.pix_stride;
+    const float4 *myn = &nb[(2 * tyr + R) * HP2 + (lx + R)];
+
+    __syncthreads();
+    const int wx0 = bbox[0], wy0 = bbox[1];
+    const int wh = bbox[3] - wy0 + 1;
+    const bool fits = bbox[2] - wx0 + 1 <= WP && wh <= WROWS;     // block-uniform
+    if (fits) {
+        // records of the fast path: everything the blend needs in one word (each thread converts its own records)
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int q = tid + j * NTHR;
+            if (q < NH2) {
+                const int rec = samp_i[q];
+                const int valid = (rec >> 26) & 1;
+                const int xl = rec & 0xfff, yt = (rec >> 12) & 0xfff;
+                const int wi = valid ? (yt - wy0) * WP + (xl - wx0) : 0;
+                const int hy = q / HW2, hx = q - hy * HW2;
+                samp_f[q] = wi | ((rec >> 24) & 3) << 10 | (hy * HP2 + hx) << 12 | valid << 22;
+            }
+        }
+    }
+    // LDS-DMA of one half chunk's window: instruction k moves rows 2k, 2k + 1 (lane = (row parity, column)), wave 0 the
+    // even k, wave 1 the odd ones; columns past the image edge re-read the edge pixel (never used)
+    const int wv = tid >> 6, ln = tid & 63;
+    const int d_gx = min(wx0 + (ln & 31), p.w - 1);
+    // (inline asm: behind the builtin the compiler waits vmcnt(0) before the next ds_read of ANY LDS array -- here the first
+    // operand read of the FMA phase -- and the round trip would not overlap anything.  The DMA is ordered against the
+    // window's readers by the two barriers of a half chunk and awaited by the explicit vmcnt(0) at its top.)
+    const unsigned win_lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>(win + wv * 64)));
+#define B2F_WIN_DMA(hc_)                                                                            \
+    do {                                                                                            \
+        const float *src__ = nbr + (size_t)((hc_) >> 1) * p.chunk_stride + 4 * ((hc_) & 1);         \
+        _Pragma("unroll") for (int k2 = 0; k2 < WROWS / 4; ++k2) {                                  \
+            const int gy = min(wy0 + 4 * k2 + 2 * wv + (ln >> 5), p.h - 1);                         \
+            const float *a = src__ + (size_t)(gy * p.w + d_gx) * p.pix_stride;                      \
+            if (4 * k2 < wh && !(B2F_WIN_ABLATE & 1))                                               \
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"     \
+                             :: "v"(a), "s"(win_lds + k2 * 2048u) : "memory", "m0");                \
+        }                                                                                           \
+    } while (0)
+
+    const int nhalf = (p.C >> 3) * 2;
+    float4 rc0 = *reinterpret_cast<const float4 *>(refp0), rc1 = *reinterpret_cast<const float4 *>(refp1);
+    if (fits) B2F_WIN_DMA(0);
+    for (int hc = 0; hc < nhalf; ++hc) {
+        // vmcnt(0): this wave's share of the window (and the reference pixels) has landed -- a wait the compiler sees, so
+        // that it knows nothing of its own is in flight below and places no vmcnt wait of its own between the DMA issue
+        // and the end of the FMA phase (its counts do not include the inline-asm DMA: any such wait would drain it)
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (fits) {
+            // ---- blend the warped halo plane from the window (the DMA of this half chunk was issued a phase ago)
+            // (no branch inside: the five items' LDS reads are in flight together; only the last item's write is predicated)
+#pragma unroll
+            for (int j = 0; j < ((B2F_WIN_ABLATE & 2) ? 0 : NG); ++j) {
+                const int q = min(tid + j * NTHR, NH2 - 1);
+                const int f = samp_f[q];
+                const float2 wxy = samp_w[q];
+                const int wi = f & 1023, dx = (f >> 10) & 1, dy = ((f >> 11) & 1) * WP;
+                const float4 tl = win[wi], tr = win[wi + dx], bl = win[wi + dy], br = win[wi + dy + dx];
+                const float wx = wxy.x, wy = wxy.y;
+                float4 w4 = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
+                if (!((f >> 22) & 1)) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v;
+                v.x = fmaf(w4.w, br.x, fmaf(w4.z, bl.x, fmaf(w4.y, tr.x, w4.x * tl.x)));
+                v.y = fmaf(w4.w, br.y, fmaf(w4.z, bl.y, fmaf(w4.y, tr.y, w4.x * tl.y)));
+                v.z = fmaf(w4.w, br.z, fmaf(w4.z, bl.z, fmaf(w4.y, tr.z, w4.x * tl.z)));
+                v.w = fmaf(w4.w, br.w, fmaf(w4.z, bl.w, fmaf(w4.y, tr.w, w4.x * tl.w)));
+                if (j < NG - 1 || tid + j * NTHR < NH2) nb[(f >> 12) & 1023] = v;
+            }
+            __syncthreads();
+        } else {
+            // ---- fallback: taps straight from memory (the flow spreads this tile's taps over more than the window holds)
+            const float *src0 = nbr + (size_t)(hc >> 1) * p.chunk_stride + 4 * (hc & 1);
+#pragma unroll 1
+            for (int j = 0; j < NG; ++j) {
+                const int q = tid + j * NTHR;
+                if (q < NH2) {
+                    const int rec = samp_i[q];
+                    const float2 wxy = samp_w[q];
+                    const bool valid = (rec >> 26) & 1;
+                    const int xl = rec & 0xfff, yt = (rec >> 12) & 0xfff;
+                    const float *src = src0 + (size_t)(yt * p.w + xl) * p.pix_stride;
+                    const int dx = ((rec >> 24) & 1) * p.pix_stride, dy = ((rec >> 25) & 1) * p.w * p.pix_stride;
+                    const float4 tl = *reinterpret_cast<const float4 *>(src), tr = *reinterpret_cast<const float4 *>(src + dx);
+                    const float4 bl = *reinterpret_cast<const float4 *>(src + dy), br = *reinterpret_cast<const float4 *>(src + dy + dx);
+                    const float wx = wxy.x, wy = wxy.y;
+                    float4 w4 = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
+                    if (!valid) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 v;
+                    v.x = fmaf(w4.w, br.x, fmaf(w4.z, bl.x, fmaf(w4.y, tr.x, w4.x * tl.x)));
+                    v.y = fmaf(w4.w, br.y, fmaf(w4.z, bl.y, fmaf(w4.y, tr.y, w4.x * tl.y)));
+                    v.z = fmaf(w4.w, br.z, fmaf(w4.z, bl.z, fmaf(w4.y, tr.z, w4.x * tl.z)));
+                    v.w = fmaf(w4.w, br.w, fmaf(w4.z, bl.w, fmaf(w4.y, tr.w, w4.x * tl.w)));
+                    const int hy = q / HW2, hx = q - hy * HW2;
+                    nb[hy * HP2 + hx] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // the window and the reference pixels of the next half chunk: in flight under the FMAs
+        const float4 ra = rc0, rb = rc1;
+        if (fits && hc + 1 < nhalf) B2F_WIN_DMA(hc + 1);
+        {
+            const int hn = min(hc + 1, nhalf - 1);      // (the last iteration re-reads its own: no branch around the loads)
+            const size_t o = (size_t)(hn >> 1) * p.chunk_stride + 4 * (hn & 1);
+            rc0 = *reinterpret_cast<const float4 *>(refp0 + o);
+            rc1 = *reinterpret_cast<const float4 *>(refp1 + o);
+        }
+        // ---- correlate: 10 neighbour rows f = -4..5; row f is qy = -f of the upper pixel and qy = 1 - f of the lower one
+#pragma unroll
+        for (int st = 0; st < ((B2F_WIN_ABLATE & 4) ? 0 : 10); ++st) {
+            const int f = st - 4;
+            float4 cur[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) cur[j] = myn[f * HP2 - (j - 4)];   // qx = j - 4
+            if (f <= 4) {
+                const int qy = -f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float a = acc0[j * 9 + qy + 4];
+                    a = fmaf(ra.x, cur[j].x, a);
+                    a = fmaf(ra.y, cur[j].y, a);
+                    a = fmaf(ra.z, cur[j].z, a);
+                    a = fmaf(ra.w, cur[j].w, a);
+                    acc0[j * 9 + qy + 4] = a;
+                }
+            }
+            if (f >= -3) {
+                const int qy = 1 - f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float a = acc1[j * 9 + qy + 4];
+                    a = fmaf(rb.x, cur[j].x, a);
+                    a = fmaf(rb.y, cur[j].y, a);
+                    a = fmaf(rb.z, cur[j].z, a);
+                    a = fmaf(rb.w, cur[j].w, a);
+                    acc1[j * 9 + qy + 4] = a;
+                }
+            }
+        }
+    }
+#undef B2F_WIN_DMA
+
+    // ---- scale by 1/C (output:div(N), CostVolMulti.lua:100) and store the record slots of both pixels
+    const float cf = (float)p.C, inv = 1.f / cf;
+    auto store_px = [&](float *acc, bool valid, int py) {
+        if (!valid) return;
+        if ((B2F_WIN_ABLATE & 8) && acc[0] != 12345.678f) return;
+#pragma unroll
+        for (int c = 0; c < 81; ++c) acc[c] = POW2 ? acc[c] * inv : acc[c] / cf;
+        const size_t pix = (size_t)py * p.w + px;
+        float *o = p.out + (size_t)b * p.out_img_stride + pix * p.out_pix_stride;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            float4 lo, hi;
+            if (dir == 0) {
+                lo = make_float4(acc[8 * j], acc[8 * j + 1], acc[8 * j + 2], acc[8 * j + 3]);
+                hi = make_float4(acc[8 * j + 4], acc[8 * j + 5], acc[8 * j + 6], acc[8 * j + 7]);
+            } else {   // the bwd thread accumulated the mirrored window: acc[c'] holds bwd channel 80 - c'
+                lo = make_float4(acc[80 - 8 * j], acc[79 - 8 * j], acc[78 - 8 * j], acc[77 - 8 * j]);
+                hi = make_float4(acc[76 - 8 * j], acc[75 - 8 * j], acc[74 - 8 * j], acc[73 - 8 * j]);
+            }
+            float *oc = o + (size_t)(dir * 10 + j) * p.out_chunk_stride;
+            *reinterpret_cast<float4 *>(oc) = lo;
+            *reinterpret_cast<float4 *>(oc + 4) = hi;
+        }
+        float *ol = o + (size_t)20 * p.out_chunk_stride;   // last chunk: [fwd80, bwd80, u, v, ub, vb, 0, 0]
+        if (dir == 0) {
+            ol[0] = acc[80];
+        } else {
+            const size_t fp = ((size_t)b * p.h * p.w + pix) * 2;
+            float2 f = make_float2(0.f, 0.f), fb = make_float2(0.f, 0.f);
+            if (p.flow) f = *reinterpret_cast<const float2 *>(p.flow + fp);
+            if (p.flow_b) fb = *reinterpret_cast<const float2 *>(p.flow_b + fp);
+            ol[1] = acc[0];
+            ol[2] = f.x; ol[3] = f.y;
+            *reinterpret_cast<float4 *>(ol + 4) = make_float4(fb.x, fb.y, 0.f, 0.f);
+        }
+    };
+    store_px(acc0, v0, py0);
+    store_px(acc1, v1, py0 + 1);
+}
+
 hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
 {
     if (p_in.C % 8 != 0 || p_in.pix_stride % 4 != 0 || p_in.chunk_stride % 4 != 0 || p_in.out_pix_stride % 4 != 0 ||
@@ -565,8 +857,17 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     //   2  the same with both directions in one 256-thread block (two blocks per CU): 0.757 / 0.318 / 0.115
     //   1  one pixel per thread, all 24 gather loads of a chunk in flight: at most one round of two blocks per CU
     //   0  one pixel per thread, 8 x 16 tiles, three blocks per CU: in between
-    const int variant = p.variant >= 0 ? p.variant : (p.ablate ? 0 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
-    if (variant == 2) {
+    //   4  variant 3 with the source window staged in LDS by LDS-DMA and the blend read from LDS (see its header); maps of
+    //      up to 4096 x 4096 pixels (12-bit tap coordinates in its sampling records).  Opt-in (corr_variant = 4): measured
+    //      0.72 / 0.30 / 0.108 ms at levels 3 / 4 / 5 against 0.69 / 0.29 / 0.113 of variant 3 -- the DMA round trip does
+    //      hide under the FMAs (ablating it saves 0.03 ms), but the half-chunk phases double the barriers and the
+    //      per-phase LDS latency chains (profiles/r02_corr_experiments.txt (10))
+    const bool win_ok = p.w <= 4096 && p.h <= 4096;
+    const int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant) : (p.ablate ? 0 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+    if (variant == 4) {
+        if (pow2) hipLaunchKernelGGL((warp_costvol_win_kernel<true>), dim3(2 * g2.x), dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_win_kernel<false>), dim3(2 * g2.x), dim3(128), 0, s, p);
+    } else if (variant == 2) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 2>), g2, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 2>), g2, dim3(256), 0, s, p);
     } else if (variant == 3) {

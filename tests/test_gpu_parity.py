@@ -117,7 +117,7 @@ def test_conv3x3_transpose_detecting(hard):
         np.testing.assert_allclose(got, O.conv3x3(x, wt, np.zeros(68, np.float32), 1, False), rtol=0, atol=2e-5)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["corr-regular", "corr-latency", "corr-two-pixel", "corr-two-pixel-one-direction"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["corr-regular", "corr-latency", "corr-two-pixel", "corr-two-pixel-one-direction", "corr-window-staged"])
 def corr_variant(request, hard):
     """Both instantiations of the warp + cost-volume kernel (the launcher would pick the latency variant for every
     test-sized launch)."""

@@ -1,6 +1,6 @@
 """A/B timing of the warp + cost-volume kernel variants inside the real forward pass (GPU box only): per-level
 HIP-event times of warp_costvol for every (variant, ablate) pair given on the command line, batch 16 x 3x1024x1920.
-    python tools/corr_ab.py 0:0 1:0 2:0 0:1 0:2 0:4      # variant:ablate_bits (variant 0 regular, 1 latency, 2 two-pixel; ablation: variant 0 only)
+    python tools/corr_ab.py 0:0 1:0 2:0 0:1 0:2 0:4      # variant:ablate_bits (variant 0 regular, 1 latency, 2 two-pixel, 3 one direction per block, 4 window-staged; ablation: variant 0 only)
 Ablated runs compute wrong results (profiling only)."""
 import sys
 sys.path.insert(0, ".")
