@@ -99,6 +99,23 @@ def test_conv3x3_wino4_persistent_blocks(hard, ci, co, h, w, blocks):
     assert np.array_equal(got, one_tile)
 
 
+@pytest.mark.parametrize("scale", [1e-3, 30.0, 1e3])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 33, 65), (200, 96, 40, 70)])
+def test_conv3x3_wino4_activation_scale(hard, scale, ci, co, h, w):
+    """The F(4x4) transforms (coefficients up to 8) amplify fp32 rounding RELATIVE to the activations: the error bar of
+    test_conv3x3 must hold in proportion at any activation scale (trained models see activations far from unit variance)."""
+    r = _rng(int(ci + co + scale))
+    x = (r.standard_normal((2, ci, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = (r.standard_normal(co, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    for persistent in (0, 3):
+        with hard.options(wino4_persistent=persistent):
+            got = ops.conv3x3(hard, x, wt, b, 1, True)
+        exp = O.conv3x3(x, wt, b, 1, True)
+        np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1.5e-4 * scale)
+        assert np.abs(got - exp).mean() < 5e-6 * scale
+
+
 def test_conv3x3_transpose_detecting(hard):
     """asymmetric single-tap kernels: catches swapped rows/cols, taps or channels."""
     x = np.arange(2 * 8 * 6 * 10, dtype=np.float32).reshape(2, 8, 6, 10) / 100
@@ -225,6 +242,39 @@ def test_compute_flow_end_to_end(hard, soft, corr_variant, which, H, Wd):
     near = np.abs(onet - 0.6666) < 1e-3
     assert ((fo != efo) & ~near[1:2]).sum() == 0
     assert ((bo != ebo) & ~near[0:1]).sum() == 0
+
+
+@pytest.mark.parametrize("which,H,Wd,bias", [("hard", 128, 192, (0.6, -0.4)), ("soft", 192, 320, (-0.5, 0.7)), ("hard", 128, 192, (3.0, 2.0))])
+def test_compute_flow_large_displacements(which, H, Wd, bias):
+    """Random weights give flows of a fraction of a pixel; trained models move features by many pixels.  Here the last layer of
+    every flow decoder carries a bias, so every level predicts flow = bias + network term: the warps of the next level sample
+    3 .. 15 pixels (level-3 units) away -- through the border clamp for a large part of the map at the coarse levels, and past
+    the 32 x 32 window of the window-staged cost-volume variant for the largest bias (its gather fallback).  Same bar as the
+    other end-to-end tests, on every cost-volume instantiation."""
+    past = which == "soft"
+    flat = W.random_init(7, past, 1.0)
+    lay, n = W.layout(past)
+    for name, shape, off in lay:
+        if name.endswith(".conv6.b") and (".flow." in name or ".past." in name):
+            sign = 1.0 if ".flow." in name else -1.0
+            flat[off:off + 2] = np.asarray(bias, np.float32) * sign
+    r = _rng(H * 3 + Wd)
+    im1, im2, im3 = _triplet(r, H, Wd)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(im1, im2, im3, flat, past, want_net=True)
+    assert np.abs(eflow).max() > 0.3
+    m = back2future.Model("random:%s:7:1.0" % which)
+    try:
+        m.set_weights(flat)
+        for variant in (-1, 0, 3, 4):
+            with m.options(corr_variant=variant):
+                flow, fo, bo = m.computeFlow(im1, im2, im3)
+            d = np.abs(flow - eflow)
+            epe = np.sqrt(((flow - eflow) ** 2).sum(0)).mean()
+            assert d.max() <= 1e-3 and epe <= 1e-3, (variant, d.max(), epe)
+            near = np.abs(onet - 0.6666) < 1e-3
+            assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
+    finally:
+        m.close()
 
 
 @pytest.mark.parametrize("min_px,adaptive", [(0, 0), (1000000, 0), (4096, 1)])
