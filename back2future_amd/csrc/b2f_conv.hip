@@ -295,7 +295,8 @@ static hipError_t launch_t(const ConvLaunch &p, hipStream_t s)
 {
     using G = ConvGeom<S, TW, NW>;
     const size_t lds = 2 * sizeof(f32x4) * (G::A_F4 + 9 * 2 * NT * 32);
-    static bool attr_done = false;   // one flag per template instance
+    static bool attr_done_dev[64] = {false};
+    bool &attr_done = attr_done_dev[attr_slot()];   // one flag per template instance
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_mfma<S, NT, TW, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -104,6 +104,14 @@ struct CorrLaunch {
     int ablate = 0;                          // profiling only (option corr_ablate): 1 no gather loads, 2 no FMAs, 4 no stores, 8 no XCD remap
     int variant = -1;                        // -1 auto, 0 regular, 1 latency, 2 two-pixel, 3 two-pixel one-direction-per-block instantiation (same bits)
 };
+// hipFuncSetAttribute is per device: launchers keep one "done" flag per device (b2f_init_multi drives several GPUs from one
+// process, one worker thread each); returns the slot of the current device
+inline int attr_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev & 63;
+}
 #ifdef __HIPCC__
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one
 // contiguous range of logical work items instead (bijective for any grid size; placement only affects speed).

@@ -350,7 +350,8 @@ static hipError_t launch_wino_t(const ConvLaunch &p, int nb0, int nblk, hipStrea
 {
     using namespace wino;
     constexpr int lds = lds_bytes(NT);
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {false};
+    bool &attr_done = attr_done_dev[attr_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino<NT, NTV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -1199,7 +1199,8 @@ template <int NTV>
 static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
 {
     using namespace wino4;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {false};
+    bool &attr_done = attr_done_dev[attr_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4<NTV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1227,7 +1228,8 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     if (p.w4_persist) {
         // persistent form: one block per CU, worth it from two tiles per block
         static int n_cu = 0;
-        static bool pattr_done = false;
+        static bool pattr_done_dev[64] = {false};
+        bool &pattr_done = pattr_done_dev[attr_slot()];
         if (!n_cu) {
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
