@@ -8,16 +8,6 @@
 namespace b2f {
 namespace {
 
-__device__ __forceinline__ void top_left_b(float coord, int size, int &pt, float &wt)
-{
-    // getTopLeft, BilinearSamplerBHWD.cu:6-20
-    float c = coord;
-    if (c < 0.f) c = 0.f;
-    if (c > (float)(size - 1)) c = (float)(size - 1);
-    const float fl = floorf(c);
-    pt = (int)fl;
-    wt = 1.f - (c - fl);
-}
 
 // One half-wave (32 lanes) per output pixel, lanes stride the channels by 32 exactly as the reference's 32 x 16 blocks do
 // (BilinearSamplerBHWD.cu:231), the four dot products are reduced with a butterfly whose lane-0 association equals
@@ -38,8 +28,8 @@ __global__ __launch_bounds__(256) void warp_bhwd_backward_kernel(const float *im
     const float2 g = *reinterpret_cast<const float2 *>(grid + pix * 2);
     int xl, yt;
     float xw, yw;
-    top_left_b(g.x + (float)xOut, iw, xl, xw);
-    top_left_b(g.y + (float)yOut, ih, yt, yw);
+    bhwd_top_left(g.x + (float)xOut, iw, xl, xw);
+    bhwd_top_left(g.y + (float)yOut, ih, yt, yw);
     const bool x1 = xl + 1 <= iw - 1, y1 = yt + 1 <= ih - 1;   // the top-left tap is always inside (coordinates are clamped)
     const size_t tl = (((size_t)b * ih + yt) * iw + xl) * C;
     const size_t tr = tl + C, bl = tl + (size_t)iw * C, br = bl + C;

@@ -60,16 +60,6 @@ struct SampIdx {
 };
 }  // namespace
 
-__device__ __forceinline__ void top_left(float coord, int size, int &pt, float &wt)
-{
-    // getTopLeft, BilinearSamplerBHWD.cu:6-20
-    float c = coord;
-    if (c < 0.f) c = 0.f;
-    if (c > (float)(size - 1)) c = (float)(size - 1);
-    const float fl = floorf(c);
-    pt = (int)fl;
-    wt = 1.f - (c - fl);
-}
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8 (8 XCDs, private L2s), so
 // with the natural order the 3x halo overlap of neighbouring tiles is re-fetched from the fabric
@@ -127,8 +117,8 @@ __global__ __launch_bounds__(256, LAT ? 2 : 3) void warp_costvol_kernel(const Co
                 const float u = fl[j].x * k, v = fl[j].y * k;
                 int xl, yt;
                 float wx, wy;
-                top_left(u + (float)x, p.w, xl, wx);
-                top_left(v + (float)y, p.h, yt, wy);
+                bhwd_top_left(u + (float)x, p.w, xl, wx);
+                bhwd_top_left(v + (float)y, p.h, yt, wy);
                 si.idx = (yt * p.w + xl) * p.pix_stride;   // float offset of the top-left tap inside the image plane
                 si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
                 wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
@@ -381,8 +371,8 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
                     const float u = fl[j].x * k, v = fl[j].y * k;
                     int xl, yt;
                     float wx, wy;
-                    top_left(u + (float)x, p.w, xl, wx);
-                    top_left(v + (float)y, p.h, yt, wy);
+                    bhwd_top_left(u + (float)x, p.w, xl, wx);
+                    bhwd_top_left(v + (float)y, p.h, yt, wy);
                     si.idx = (yt * p.w + xl) * p.pix_stride;
                     si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
                     wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
@@ -631,8 +621,8 @@ __global__ __launch_bounds__(128, 2) void warp_costvol_win_kernel(const CorrLaun
                     const float u = fl[j].x * k, v = fl[j].y * k;
                     int xl, yt;
                     float wx, wy;
-                    top_left(u + (float)x, p.w, xl, wx);
-                    top_left(v + (float)y, p.h, yt, wy);
+                    bhwd_top_left(u + (float)x, p.w, xl, wx);
+                    bhwd_top_left(v + (float)y, p.h, yt, wy);
                     const int fx = (xl + 1 <= p.w - 1) ? 1 : 0, fy = (yt + 1 <= p.h - 1) ? 1 : 0;
                     rec = xl | yt << 12 | fx << 24 | fy << 25 | 1 << 26;
                     wxy = make_float2(wx, wy);
@@ -862,8 +852,15 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     //      0.72 / 0.30 / 0.108 ms at levels 3 / 4 / 5 against 0.69 / 0.29 / 0.113 of variant 3 -- the DMA round trip does
     //      hide under the FMAs (ablating it saves 0.03 ms), but the half-chunk phases double the barriers and the
     //      per-phase LDS latency chains (profiles/r02_corr_experiments.txt (10))
+    //   5  the persistent "unit" form of b2f_corr5.hip (C a multiple of 32; other C run variant 3)
     const bool win_ok = p.w <= 4096 && p.h <= 4096;
-    const int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant) : (p.ablate ? 0 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+    // default: by the map size for the small maps (so that a triplet's kernel does not depend on the batch it is computed in; the
+    // instantiations are bit-identical anyway): the unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet: 0.053 / 0.039
+    // ms against 0.060 / 0.081 at batch 16), else by the launch size
+    int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
+                  : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 5 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+    if (variant == 5 && !warp_costvol_unit_supported(p)) variant = 3;
+    if (variant == 5) return launch_warp_costvol_unit(p, s);
     if (variant == 4) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_win_kernel<true>), dim3(2 * g2.x), dim3(128), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_win_kernel<false>), dim3(2 * g2.x), dim3(128), 0, s, p);

@@ -38,15 +38,6 @@ hipError_t launch_pack_input(const float *in, int normalize, int B, int H, int W
     return hipGetLastError();
 }
 
-__device__ __forceinline__ void top_left_g(float coord, int size, int &pt, float &wt)
-{
-    float c = coord;   // getTopLeft, BilinearSamplerBHWD.cu:6-20
-    if (c < 0.f) c = 0.f;
-    if (c > (float)(size - 1)) c = (float)(size - 1);
-    const float fl = floorf(c);
-    pt = (int)fl;
-    wt = 1.f - (c - fl);
-}
 
 // ---- nn.BilinearSamplerBHWD forward, CUDA semantics (BilinearSamplerBHWD.cu:41-115);
 // one thread per (output pixel, channel): consecutive lanes = consecutive channels. ----
@@ -66,8 +57,8 @@ __global__ void warp_nhwc_kernel(const float *img, long img_stride, int pix_stri
     const float2 g = *reinterpret_cast<const float2 *>(grid + pix * 2);
     int xl, yt;
     float wx, wy;
-    top_left_g(g.x * k + (float)x, iw, xl, wx);
-    top_left_g(g.y * k + (float)y, ih, yt, wy);
+    bhwd_top_left(g.x * k + (float)x, iw, xl, wx);
+    bhwd_top_left(g.y * k + (float)y, ih, yt, wy);
     const float *src = img + (size_t)b * img_stride + ((size_t)yt * iw + xl) * pix_stride + c;
     const bool x1 = xl + 1 <= iw - 1, y1 = yt + 1 <= ih - 1;
     const float tl = src[0];
@@ -185,8 +176,8 @@ __global__ void warp_image_planar_kernel(const float *img8, const float *flow, f
     const float u = flow[(b * 2) * hw + p] * k, v = flow[(b * 2 + 1) * hw + p] * k;
     int xl, yt;
     float wx, wy;
-    top_left_g(u + (float)x, W, xl, wx);
-    top_left_g(v + (float)y, H, yt, wy);
+    bhwd_top_left(u + (float)x, W, xl, wx);
+    bhwd_top_left(v + (float)y, H, yt, wy);
     const float *src = img8 + (b * hw + (size_t)yt * W + xl) * kImgC;
     const bool x1 = xl + 1 <= W - 1, y1 = yt + 1 <= H - 1;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -423,8 +414,8 @@ __global__ void warp_input_planar_kernel(const float *in, int normalize, int fra
     const float u = flow[(b * 2) * hw + p] * k, v = flow[(b * 2 + 1) * hw + p] * k;
     int xl, yt;
     float wx, wy;
-    top_left_g(u + (float)x, W, xl, wx);
-    top_left_g(v + (float)y, H, yt, wy);
+    bhwd_top_left(u + (float)x, W, xl, wx);
+    bhwd_top_left(v + (float)y, H, yt, wy);
     const int dx = (xl + 1 <= W - 1) ? 1 : 0, dy = (yt + 1 <= H - 1) ? W : 0;   // weight is 0 when folded
     const float w00 = wx * wy, w01 = (1.f - wx) * wy, w10 = wx * (1.f - wy), w11 = (1.f - wx) * (1.f - wy);
     const float mean[3] = {0.485f, 0.456f, 0.406f};

@@ -13,16 +13,6 @@
 namespace b2f {
 namespace {
 
-__device__ __forceinline__ void top_left_q(float coord, int size, int &pt, float &wt)
-{
-    // getTopLeft, BilinearSamplerBHWD.cu:6-20
-    float c = coord;
-    if (c < 0.f) c = 0.f;
-    if (c > (float)(size - 1)) c = (float)(size - 1);
-    const float fl = floorf(c);
-    pt = (int)fl;
-    wt = 1.f - (c - fl);
-}
 
 // element (b, c, pix) of a chunk-planar tensor with `chunks` 8-channel planes per image
 __device__ __forceinline__ size_t cp8_at(int b, int chunks, size_t hw, int c, size_t pix)
@@ -109,8 +99,8 @@ __global__ void warp_cp8_kernel(const float *img, int chunks, const float *flow,
     const float2 g = *reinterpret_cast<const float2 *>(flow + ((size_t)b * hw + pix) * 2);
     int xl, yt;
     float wx, wy;
-    top_left_q(g.x * k + (float)x, w, xl, wx);
-    top_left_q(g.y * k + (float)y, h, yt, wy);
+    bhwd_top_left(g.x * k + (float)x, w, xl, wx);
+    bhwd_top_left(g.y * k + (float)y, h, yt, wy);
     const float *src = img + (((size_t)b * chunks + ch) * hw + (size_t)yt * w + xl) * 8 + c8;
     const bool x1 = xl + 1 <= w - 1, y1 = yt + 1 <= h - 1;
     const float tl = src[0];

@@ -121,11 +121,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     const int xcd = bid & 7, k = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+// getTopLeft of the CUDA sampler (BilinearSamplerBHWD.cu:6-20): the coordinate is clamped to the border FIRST, then
+// floored; wt = weight of the top / left tap.  The one definition every warp in the library uses.
+__device__ __forceinline__ void bhwd_top_left(float coord, int size, int &pt, float &wt)
+{
+    float c = coord;
+    if (c < 0.f) c = 0.f;
+    if (c > (float)(size - 1)) c = (float)(size - 1);
+    const float fl = floorf(c);
+    pt = (int)fl;
+    wt = 1.f - (c - fl);
+}
 #endif
 
 // slot of cost-volume channel c (0..80) of direction dir (0 fwd, 1 bwd) inside a record
 inline int cv_slot(int dir, int c) { return c < 80 ? dir * 80 + c : 160 + dir; }
 hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);
+// b2f_corr5.hip: the persistent "unit" form (variant 5; C a multiple of 32), same bits as the others
+bool warp_costvol_unit_supported(const CorrLaunch &p);
+hipError_t launch_warp_costvol_unit(const CorrLaunch &p, hipStream_t s);
 // generic (any odd win) single-direction cost volume, NHWC in, B x h x w x win*win out
 hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int C, int h, int w,
                                   int win, int fwd, float *out, hipStream_t s);
