@@ -678,10 +678,22 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
     c->device = device;
     c->g = g;
     {   // defaults of the tuning options may come from the environment; read here once, never on the hot path
-        auto env_int = [](const char *k, long long dflt) { const char *v = getenv(k); return v ? atoll(v) : dflt; };
+        // B2F_<OPTION NAME IN CAPITALS> seeds the option of that name (b2f_set_option keys); a value that is set but not a
+        // number (B2F_PROFILE_LAYERS=yes, or empty) counts as 1
+        auto env_int = [](const char *k, long long dflt) {
+            const char *v = getenv(k);
+            if (!v) return dflt;
+            char *end = nullptr;
+            const long long x = strtoll(v, &end, 10);
+            return end == v ? 1ll : x;
+        };
         c->wino4_min_pixels = (int)env_int("B2F_WINO4_MIN_PIXELS", c->wino4_min_pixels);
         c->adaptive_kernels = (int)env_int("B2F_ADAPTIVE_KERNELS", c->adaptive_kernels);
-        c->corr_variant = (int)env_int("B2F_CORR_LAT", c->corr_variant);
+        c->corr_variant = (int)env_int("B2F_CORR_VARIANT", env_int("B2F_CORR_LAT", c->corr_variant));   // B2F_CORR_LAT: the round-1 name
+        c->op_wino_split = (int)env_int("B2F_OP_WINO_SPLIT", c->op_wino_split);
+        c->use_graph = (int)env_int("B2F_USE_GRAPH", c->use_graph);
+        c->host_graph = (int)env_int("B2F_HOST_GRAPH", c->host_graph);
+        c->profile = (int)env_int("B2F_PROFILE", c->profile);
         c->corr_ablate = (int)env_int("B2F_CORR_ABLATE", c->corr_ablate);
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
@@ -815,6 +827,7 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_threads")) c->host_threads = value;
     else if (!strcmp(key, "host_u8")) c->host_u8 = value;
     else if (!strcmp(key, "host_ramp")) c->host_ramp = value;
+    else if (!strcmp(key, "debug_fail_next")) c->debug_fail_next = value;
     else return fail(std::string("b2f_set_option: unknown key ") + key);
     return 0;
 }
@@ -839,6 +852,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "host_threads") *value = c->host_threads;
     else if (k == "host_u8") *value = c->host_u8;
     else if (k == "host_ramp") *value = c->host_ramp;
+    else if (k == "debug_fail_next") *value = c->debug_fail_next;
     else return fail("b2f_get_option: unknown key " + k);
     return 0;
 }

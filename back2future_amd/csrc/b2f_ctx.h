@@ -229,6 +229,7 @@ struct b2f_ctx {
     long long host_subbatch_pixels = 16ll << 20;
     int host_threads = 0;          // 0 = auto
     int host_u8 = 1, host_ramp = 1;
+    int debug_fail_next = 0;       // tests: the next b2f_compute_flow* call on this context fails (cross-thread error hand-over of b2f_multi_*)
     std::map<b2f::GraphKey, hipGraphExec_t> graphs;
     // profiling
     std::vector<std::string> prof_names;

@@ -11,6 +11,7 @@
 //     buffers.  No data-path collective: computeFlow keeps no cross-sample state.
 #include "b2f_ctx.h"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -67,32 +68,48 @@ int broadcast_weights(b2f_multi *m, int *transport)
     }
     Rccl r;
     bool done = false;
+    std::string why;
     if (*transport == 1 && r.load()) {
+        // Communicators and the open group are released on every path (an early return between GroupStart and GroupEnd /
+        // CommDestroy would leak all n communicators and leave RCCL's group open for the next rebroadcast): errors are
+        // collected, the group is always closed, the communicators always destroyed, and ANY failure falls back to peer copies.
         std::vector<ncclComm_t> comms((size_t)n, nullptr);
         ncclResult_t rc = r.CommInitAll(comms.data(), n, m->devices.data());
+        hipError_t he = hipSuccess;
         if (rc == ncclSuccess) {
             rc = r.GroupStart();
-            for (int i = 0; i < n && rc == ncclSuccess; ++i) {
-                HIPCHK(hipSetDevice(m->devices[(size_t)i]));
-                rc = r.Broadcast(src, dst[(size_t)i], (size_t)count, ncclFloat, 0, comms[(size_t)i], m->ctx[(size_t)i]->stream);
+            const bool group_open = rc == ncclSuccess;
+            for (int i = 0; i < n && rc == ncclSuccess && he == hipSuccess; ++i) {
+                he = hipSetDevice(m->devices[(size_t)i]);
+                if (he == hipSuccess)
+                    rc = r.Broadcast(src, dst[(size_t)i], (size_t)count, ncclFloat, 0, comms[(size_t)i], m->ctx[(size_t)i]->stream);
             }
-            const ncclResult_t re = r.GroupEnd();
-            if (rc == ncclSuccess) rc = re;
-            for (int i = 0; i < n; ++i) {
-                HIPCHK(hipSetDevice(m->devices[(size_t)i]));
-                HIPCHK(hipStreamSynchronize(m->ctx[(size_t)i]->stream));
+            if (group_open) {
+                const ncclResult_t re = r.GroupEnd();
+                if (rc == ncclSuccess) rc = re;
             }
-            for (ncclComm_t c : comms)
-                if (c) (void)r.CommDestroy(c);
-            if (rc != ncclSuccess)
-                return api_fail(std::string("b2f_init_multi: RCCL broadcast failed: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?"));
-            done = true;
+            for (int i = 0; i < n; ++i) {          // drain every stream before the communicators go away, whatever happened
+                hipError_t e1 = hipSetDevice(m->devices[(size_t)i]);
+                if (e1 == hipSuccess) e1 = hipStreamSynchronize(m->ctx[(size_t)i]->stream);
+                if (he == hipSuccess) he = e1;
+            }
         }
+        for (ncclComm_t c : comms)
+            if (c) (void)r.CommDestroy(c);
+        if (rc == ncclSuccess && he == hipSuccess) done = true;
+        else why = rc != ncclSuccess ? std::string("RCCL: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?") : std::string("HIP: ") + hipGetErrorString(he);
     }
     if (!done) {
         *transport = 2;
-        for (int i = 1; i < n; ++i)
-            HIPCHK(hipMemcpyPeer(dst[(size_t)i], m->devices[(size_t)i], src, m->devices[0], (size_t)count * sizeof(float)));
+        for (int i = 1; i < n; ++i) {
+            if (m->devices[(size_t)i] == m->devices[0]) {
+                // two replicas on one GPU (test switch B2F_MULTI_ALLOW_DUPLICATE): a peer copy onto the same device
+                HIPCHK(hipSetDevice(m->devices[0]));
+                HIPCHK(hipMemcpy(dst[(size_t)i], src, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice));
+            } else {
+                HIPCHK(hipMemcpyPeer(dst[(size_t)i], m->devices[(size_t)i], src, m->devices[0], (size_t)count * sizeof(float)));
+            }
+        }
     }
     for (int i = 1; i < n; ++i) CHK(b2f_commit_weights(m->ctx[(size_t)i]));
     return 0;
@@ -143,7 +160,11 @@ int b2f_init_multi(const char *name_or_path, int n_gpus, const int *devices, b2f
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return api_fail("b2f_init_multi: no HIP device available (this library has no CPU fallback)");
     if (n_gpus == 0) n_gpus = ndev;   // all visible GPUs
-    if (n_gpus < 0 || n_gpus > ndev) return api_fail("b2f_init_multi: n_gpus exceeds the visible devices");
+    // Test switch (tests/test_gpu_parity.py: the N > 1 code path on a one-GPU box): B2F_MULTI_ALLOW_DUPLICATE=1 together with
+    // B2F_MULTI_TRANSPORT=peer lets a device be listed more than once -- several replicas, worker threads and shards on one GPU
+    const char *tr_env = getenv("B2F_MULTI_TRANSPORT"), *dup_env = getenv("B2F_MULTI_ALLOW_DUPLICATE");
+    const bool allow_dup = dup_env && atoi(dup_env) == 1 && tr_env && !strcmp(tr_env, "peer");
+    if (n_gpus < 0 || (n_gpus > ndev && !allow_dup) || n_gpus > 64) return api_fail("b2f_init_multi: n_gpus exceeds the visible devices");
     std::unique_ptr<b2f_multi> m(new b2f_multi());
     struct Guard {
         b2f_multi *m;
@@ -153,7 +174,7 @@ int b2f_init_multi(const char *name_or_path, int n_gpus, const int *devices, b2f
         const int d = devices ? devices[i] : i;
         if (d < 0 || d >= ndev) return api_fail("b2f_init_multi: bad device ordinal");
         for (int e : m->devices)
-            if (e == d) return api_fail("b2f_init_multi: a device is listed twice");
+            if (e == d && !allow_dup) return api_fail("b2f_init_multi: a device is listed twice");
         m->devices.push_back(d);
     }
     // replica 0 reads the file / draws the weights; the others start from a different deterministic set of the same
@@ -167,7 +188,7 @@ int b2f_init_multi(const char *name_or_path, int n_gpus, const int *devices, b2f
         CHK(b2f_init(filler.c_str(), m->devices[(size_t)i], &ci));
         m->ctx.push_back(ci);
     }
-    const char *e = getenv("B2F_MULTI_TRANSPORT");   // "peer": skip RCCL; "selftest": run the broadcast even on one GPU
+    const char *e = tr_env;   // "peer": skip RCCL; "selftest": run the broadcast even on one GPU
     if (n_gpus > 1 || (e && !strcmp(e, "selftest"))) {
         int transport = (e && !strcmp(e, "peer")) ? 2 : 1;
         CHK(broadcast_weights(m.get(), &transport));

@@ -102,6 +102,10 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
 {
     if (!c || !im1 || !im2 || !im3 || !flow || !fwd_occ || !bwd_occ) return fail("b2f_compute_flow: null argument");
     if (n <= 0 || H0 <= 0 || W0 <= 0) return fail("b2f_compute_flow: bad shape");
+    if (c->debug_fail_next) {   // tests (option debug_fail_next): one forced failure, e.g. on one replica of a b2f_multi
+        c->debug_fail_next = 0;
+        return fail("b2f_compute_flow: forced failure (option debug_fail_next)");
+    }
     const int fw = W0 - W0 % 64, fh = H0 - H0 % 64;   // back2future.lua:54-67
     if (fw <= 0 || fh <= 0) return fail("b2f_compute_flow: image smaller than 64 pixels");
     CHK(check_shape(1, fh, fw));

@@ -1227,9 +1227,10 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     dim3 grid((unsigned)(tiles * p.nimg * nblk));
     if (p.w4_persist) {
         // persistent form: one block per CU, worth it from two tiles per block
-        static int n_cu = 0;
+        static int n_cu_dev[64] = {0};                  // per device, like the attribute flags (b2f_init_multi: one worker thread per GPU)
         static bool pattr_done_dev[64] = {false};
         bool &pattr_done = pattr_done_dev[attr_slot()];
+        int &n_cu = n_cu_dev[attr_slot()];
         if (!n_cu) {
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;

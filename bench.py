@@ -48,58 +48,58 @@ def conv_flops_per_px():
 
 
 def conv_layers(H, W):
-    """Every conv of the pruned computeFlow graph as (cin, cout, stride, out_h, out_w, calls per triplet): the three
-    siamese towers, the flow decoders of levels 7..3 and the occlusion decoder of level 3."""
+    """Every conv of the pruned computeFlow graph as (cin, cout, stride, out_h, out_w, calls per triplet, cin as the kernels see it):
+    the three siamese towers, the flow decoders of levels 7..3 and the occlusion decoder of level 3.  Input
+    channels are padded to 8; a decoder's first layer reads the 168-slot cost-volume record (flow inside) + the reference features."""
     out = []
     for l in range(2, 8):
         h, w = H >> (l - 1), W >> (l - 1)
-        out.append((FEAT[l - 1], FEAT[l], 2, h, w, 3))
-        out.append((FEAT[l], FEAT[l], 1, h, w, 3))
+        out.append((FEAT[l - 1], FEAT[l], 2, h, w, 3, (FEAT[l - 1] + 7) // 8 * 8))
+        out.append((FEAT[l], FEAT[l], 1, h, w, 3, FEAT[l]))
     for l in range(7, 2, -1):
         h, w = H >> (l - 1), W >> (l - 1)
         ci = 162 if l == 7 else 162 + FEAT[l] + 2
+        cip = 168 if l == 7 else 168 + FEAT[l]
         for co in DEC:
-            out.append((ci, co, 1, h, w, 2 if l == 3 else 1))
-            ci = co
+            out.append((ci, co, 1, h, w, 2 if l == 3 else 1, cip))
+            ci = cip = co
     return out
 
 
-def conv_kernel_of(ci, co, stride, h, w, nimg=48):
-    """Kernel class a layer runs on -- the rule of b2f_api.hip (wino_mode, run_conv) with the default switches; nimg =
-    images of the launch (3 B for the siamese towers, B for a decoder).  The Winograd variant is chosen by block
-    rounds on 256 CUs: F(4x4) blocks 16 x 32 pixels x 64 outputs cost 60 each, F(2x2) blocks 8 x 16 x 64 cost 20 alone /
-    40 per co-resident pair, F(2x2) blocks of one 32-output N tile 13 / 26."""
-    if ci == 3:
-        return "conv_first"
-    if stride == 1 and co == 2:
-        return "conv3x3_narrow2"
-    if stride == 1 and ci == 16 and co == 16:
-        return "conv3x3_c16"
-    if stride == 1 and co >= 32 and co % 4 == 0:
-        tiles2 = nimg * ((h + 7) // 8) * ((w + 15) // 16)
-        b4 = nimg * ((h + 15) // 16) * ((w + 31) // 32) * ((co + 63) // 64)
-        nblk2 = 1 if co <= 32 else (co + 63) // 64
-        b2, b2s = tiles2 * nblk2, tiles2 * ((co + 31) // 32)
-        t4 = 60 * ((b4 + 255) // 256)
-        t2 = 20 if b2 <= 256 else 40 * ((b2 + 511) // 512)
-        t2s = t2 if co <= 32 else (13 if b2s <= 256 else 26 * ((b2s + 511) // 512))
-        return "conv3x3_wino" if min(t2, t2s) < t4 else "conv3x3_wino4"
-    if stride == 1 and co >= 16:
-        return "conv3x3_wino"
-    return "conv3x3_s%d" % stride
+MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "D1": "conv3x3_s1", "D2": "conv3x3_s2"}
 
 
-def conv_flops_by_kernel(H, W, B=16):
-    """Per kernel class and triplet (in a batch of B): (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes).  Executed:
-    F(4x4) 36/16 MACs per output and channel pair, F(2x2) 16/4, direct 9; input channels padded to 8 (the decoder's
-    first layer reads the 168-slot cost-volume record), outputs to 32 (16 for the 16 -> 16 kernel); VALU kernels 0."""
+def layer_kernels(model, step, torch):
+    """Kernel class of every conv layer AS THE LIBRARY RAN IT: one eager pass with option profile_layers, whose rows are named
+    conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
+    C16 = 16 -> 16 kernel, D1 / D2 = direct kernel stride 1 / 2).  Returns {(cin_padded, cout, H_in, W_in): class}."""
+    model.set_option("use_graph", 0)
+    model.set_option("profile_layers", 1)
+    model.set_option("profile", 1)
+    model.profile_reset()
+    step()
+    torch.cuda.synchronize()
+    rows = model.profile_read()
+    model.set_option("profile", 0)
+    model.set_option("profile_layers", 0)
+    model.profile_reset()
+    import re
+    out = {}
+    for name, (ms, n) in rows.items():
+        m = re.match(r"^conv(W4|W2|N2|C16|D1|D2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
+            out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
+    return out
+
+
+def conv_flops_by_kernel(H, W, kernels):
+    """Per kernel class and triplet: (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes); `kernels` = the
+    library's own choice per layer (layer_kernels).  Executed: F(4x4) 36/16 MACs per output and channel pair, F(2x2) 16/4, direct 9;
+    input channels as conv_layers pads them, outputs to 32 (16 for the 16 -> 16 kernel); VALU kernels 0."""
     alg, exe = {}, {}
-    for ci, co, stride, h, w, calls in conv_layers(H, W):
-        k = conv_kernel_of(ci, co, stride, h, w, nimg=3 * B if calls == 3 else B)
+    for ci, co, stride, h, w, calls, cip in conv_layers(H, W):
+        k = "conv_first" if ci == 3 else kernels[(cip, co, h * stride, w * stride)]
         n = float(h * w * calls)
-        cip = (ci + 7) // 8 * 8
-        if ci >= 162:
-            cip = 168 + (ci - 162 - 2 if ci > 162 else 0)          # record (168 slots, flow inside) + reference features
         cop = (co + 31) // 32 * 32
         per_out = {"conv3x3_wino4": 36.0 / 16.0, "conv3x3_wino": 16.0 / 4.0}.get(k, 9.0)
         e = 2.0 * per_out * cip * cop
@@ -110,12 +110,6 @@ def conv_flops_by_kernel(H, W, B=16):
         alg[k] = alg.get(k, 0.0) + 2.0 * 9.0 * ci * co * n
         exe[k] = exe.get(k, 0.0) + e * n
     return alg, exe
-
-
-def conv_executed_flops_per_px():
-    """FLOPs the MFMA pipe actually executes per full-resolution pixel at the bench size (see conv_flops_by_kernel)."""
-    _, exe = conv_flops_by_kernel(1024, 1920)
-    return sum(exe.values()) / (1024.0 * 1920.0)
 
 
 def corr_bytes_per_px():
@@ -239,9 +233,15 @@ def main():
                          "0: eager launches.  Per-kernel times always come from a second, un-timed eager pass with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only `value` and the per-kernel profile: no compute_flow_hard_exact, two_pipelines_in_flight, host_path or CPU "
+                         "columns -- every forward pass of the process is then the same pass, which is what tools/collect_profiles.sh "
+                         "profiles (AverageNs x launches per step of its kernel stats = kernel_ms_per_step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_cpu_baseline = args.no_host_path = True
 
     import torch
     import torch.distributed as dist
@@ -319,19 +319,21 @@ def main():
     # only est[2], which computeFlow never looks at).  `value` keeps the occlusion decoder: SURVEY s8d's pruned graph.
     def step_hard_exact():
         model.forward_device(x.data_ptr(), B, H, W, flow.data_ptr(), None, est3.data_ptr(), unit_input=True, stream=stream)
-    for _ in range(3):
-        step_hard_exact()
-    torch.cuda.synchronize()
-    th0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_hard_exact()
-    torch.cuda.synchronize()
-    hard_dt = time.perf_counter() - th0
+    hard_dt = None
+    if not args.no_extras:
+        for _ in range(3):
+            step_hard_exact()
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_hard_exact()
+        torch.cuda.synchronize()
+        hard_dt = time.perf_counter() - th0
 
     # Beside `value` (never as it): two step pipelines in flight -- a second context (own arena, stream and captured graph) takes
     # every other step, so the launch-latency-bound coarse pyramid levels of one step run beside the wide kernels of the next
     two = None
-    if world == 1 and args.graph:
+    if world == 1 and args.graph and not args.no_extras:
         try:
             m2 = back2future.Model("random:hard:2:1.0", device=local_rank)
             m2.set_option("use_graph", 1)
@@ -376,6 +378,7 @@ def main():
     prof_dt = time.perf_counter() - tp0
     prof = model.profile_read()
     model.set_option("profile", 0)
+    kernels = layer_kernels(model, step, torch)       # the library's kernel class per layer (one more un-timed eager pass)
     finite = bool(torch.isfinite(flow).all().item() and torch.isfinite(occ).all().item())
 
     if rank == 0:
@@ -398,12 +401,13 @@ def main():
         }
         if bcast:
             out["weights_broadcast"] = bcast
-        out["compute_flow_hard_exact"] = {
-            "what": "same workload without the level-3 occlusion decoder: everything computeFlow() of an Ours-Hard model reads "
-                    "(flow = est[1], masks from est[3] = warped frame 1); reported beside `value`, which keeps SURVEY s8d's pruned "
-                    "graph (occlusion decoder of level 3 included)",
-            "value": world * B * args.steps / hard_dt if world == 1 else None, "unit": "triplets/s (this rank)" if world > 1 else "triplets/s",
-            "rank0_value": B * args.steps / hard_dt, "ms_per_step": 1e3 * hard_dt / args.steps}
+        if hard_dt is not None:
+            out["compute_flow_hard_exact"] = {
+                "what": "same workload without the level-3 occlusion decoder: everything computeFlow() of an Ours-Hard model reads "
+                        "(flow = est[1], masks from est[3] = warped frame 1); reported beside `value`, which keeps SURVEY s8d's pruned "
+                        "graph (occlusion decoder of level 3 included)",
+                "value": world * B * args.steps / hard_dt if world == 1 else None, "unit": "triplets/s (this rank)" if world > 1 else "triplets/s",
+                "rank0_value": B * args.steps / hard_dt, "ms_per_step": 1e3 * hard_dt / args.steps}
         if two:
             out["two_pipelines_in_flight"] = two
         if prof:
@@ -413,7 +417,7 @@ def main():
             corr_ms /= args.steps
             corr_n /= args.steps
             tr = pmc_traffic(B, H, W)
-            alg_k, exe_k = conv_flops_by_kernel(H, W, B)
+            alg_k, exe_k = conv_flops_by_kernel(H, W, kernels)
             kms = {}
             for k, (ms, n) in prof.items():                      # profile rows -> kernel classes (rows carry an _ntN suffix)
                 for cls in alg_k:
@@ -452,6 +456,9 @@ def main():
                                         "traffic_unit": "HBM bytes per step (PMC)", "traffic_source": tr.get("file"),
                                         "ms_per_step": corr_ms, "algorithmic_bytes_per_step": cb}
             out["kernel_ms_per_step"] = {k: ms / args.steps for k, (ms, n) in sorted(prof.items())}
+            out["conv_kernel_of_layer"] = {"what": "kernel class the library ran each conv layer on (cin padded, cout, input map), read back from "
+                                                   "its per-layer profile rows -- executed_flop_per_step follows from this, not from a rule restated here",
+                                           "layers": {"%dto%d_%dx%d" % k: v for k, v in sorted(kernels.items())}}
             out["profiled_pass_ms_per_step"] = 1e3 * prof_dt / args.steps
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(torch, model, H, W)

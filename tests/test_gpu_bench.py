@@ -31,6 +31,20 @@ def test_single_gpu_line_contract():
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["bound"] == "mfma"          # a fraction of a roofline, never above 1
     assert 0 < d["roofline_corrwarp"]["frac"] <= 1 and d["roofline_corrwarp"]["bound"] == "hbm"
     assert d["value"] > 0 and d["outputs_finite"]
+    # the per-layer kernel classes are read back from the library (not re-derived): every conv layer of the pruned graph is there
+    layers = d["conv_kernel_of_layer"]["layers"]
+    assert layers["16to16_64x128"] == "conv3x3_c16" and layers["32to2_32x64"] == "conv3x3_narrow2" and layers["16to32_64x128"] == "conv3x3_s2"
+    assert set(layers.values()) <= {"conv3x3_wino4", "conv3x3_wino", "conv3x3_narrow2", "conv3x3_c16", "conv3x3_s1", "conv3x3_s2"}
+    assert "compute_flow_hard_exact" in d and "two_pipelines_in_flight" in d
+
+
+def test_no_extras_line_is_the_plain_pass_only():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras"] + SMALL[:10], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("compute_flow_hard_exact", "two_pipelines_in_flight", "host_path", "cpu_baseline"):
+        assert k not in d, k
+    assert d["value"] > 0 and "roofline" in d and "kernel_ms_per_step" in d
 
 
 def test_two_ranks_share_the_gpu_over_gloo():

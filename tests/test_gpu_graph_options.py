@@ -20,6 +20,12 @@ def test_graph_options_full_table_vs_oracle(name, past):
         assert m.n_outputs == (o["levels"] - o["skip"]) * (5 if past else 4)
         p = W.random_init(11, past, 2.0, o)
         np.testing.assert_array_equal(m.get_weights(), p)         # same generator, same canonical order of this graph
+        # a bias on the last layer of every flow decoder: every level predicts a flow of several pixels (in units of its own map), so
+        # the feature / image warps sample whole pixels away and through the border clamp -- random weights alone move by < 1 px
+        for lname, shape, off in W.layout(past, o)[0]:
+            if lname.endswith(".conv6.b") and (".flow." in lname or ".past." in lname):
+                p[off:off + 2] = np.asarray((0.35, -0.25), np.float32) * (1.0 if ".flow." in lname else -1.0)
+        m.set_weights(p)
         rng = np.random.default_rng(len(name) + 7 * past)
         mlt = 1 << (o["levels"] - 1)
         H, Wd = 4 * mlt, 6 * mlt
@@ -27,13 +33,17 @@ def test_graph_options_full_table_vs_oracle(name, past):
         got = m.forward(x)
         exp = O.pwc_forward(x, p, past, _oracle_opts(o, past))
         assert len(got) == len(exp)
-        assert np.abs(exp[0]).max() > 0.02
+        assert np.abs(exp[0]).max() > 0.3
         for i, (a, b) in enumerate(zip(got, exp)):
             assert a.shape == b.shape, (i, a.shape, b.shape)
             assert np.isfinite(a).all()
-            # warped images (3-channel entries) may differ by more at sampling-cell boundaries of a 1e-6 flow difference
-            tol = 1e-3
-            assert np.abs(a - b).max() <= tol, (name, i, float(np.abs(a - b).max()))
+            if a.shape[1] == 3:
+                # warped images may differ by more at sampling-cell boundaries of a 1e-6 flow difference
+                assert np.abs(a - b).max() <= 1e-3, (name, i, float(np.abs(a - b).max()))
+            else:
+                # flows / occlusion probabilities: fp32 re-association of the Winograd transforms only (a wrong channel offset in a
+                # zero-padded JoinTable or a wrong flow-scale constant at some level would be orders of magnitude above this)
+                np.testing.assert_allclose(a, b, rtol=2e-4, atol=3e-5, err_msg="%s output %d" % (name, i))
     finally:
         m.close()
 

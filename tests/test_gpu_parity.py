@@ -694,6 +694,50 @@ def test_broadcast_weights_device_path():
         b.close()
 
 
+def test_multi_gpu_two_replicas_on_one_gpu(monkeypatch):
+    """The N > 1 code of the one-process multi-GPU entry points on the one-GPU test box: B2F_MULTI_ALLOW_DUPLICATE=1 (honoured only
+    with the peer transport) lists GPU 0 twice -> two contexts, two worker threads, two uneven shards (5 = 3 + 2), replica 1 created
+    from OTHER weights and brought in line by the peer broadcast; results bit-identical to one context; a failure on replica 1 is
+    handed over from its worker thread to the caller with the GPU named; the pair keeps working afterwards (util.lua:27-48)."""
+    import ctypes as C
+    from back2future_amd import _lib
+    monkeypatch.setenv("B2F_MULTI_TRANSPORT", "peer")
+    monkeypatch.setenv("B2F_MULTI_ALLOW_DUPLICATE", "1")
+    r = _rng(23)
+    n, H0, W0 = 5, 100, 150
+    ims = [r.random((n, 3, H0, W0), dtype=np.float32) for _ in range(3)]
+    mm = back2future.MultiModel("random:soft:5:2.0", n_gpus=2, devices=[0, 0])
+    ref = back2future.Model("random:soft:5:2.0")
+    try:
+        assert mm.n_gpus == 2 and mm.devices == [0, 0] and mm.transport == "hipMemcpyPeer"
+        sums = mm.weights_checksums()
+        assert len(sums) == 2 and sums[0] == sums[1]
+        assert back2future.shard_range(n, 0, 2) == (0, 3) and back2future.shard_range(n, 1, 2) == (3, 5)
+        exp = ref.computeFlowBatch(*ims)
+        for a, b in zip(mm.computeFlowBatch(*ims), exp):
+            np.testing.assert_array_equal(a, b)
+        by = [np.round(a * 255).astype(np.uint8) for a in ims]
+        for a, b in zip(mm.computeFlowBatch(*by), ref.computeFlowBatch(*by)):
+            np.testing.assert_array_equal(a, b)
+        # one triplet: replica 1's shard is empty, only one worker thread runs
+        for a, b in zip(mm.computeFlowBatch(*[x[:1] for x in ims]), [e[:1] for e in exp]):
+            np.testing.assert_array_equal(a, b)
+        # replica 1 fails once: the message crosses from its worker thread to the caller
+        L = _lib.lib()
+        _lib.check(L.b2f_set_option(C.c_void_p(L.b2f_multi_context(mm._h, 1)), b"debug_fail_next", 1))
+        with pytest.raises(Exception, match="GPU 0: .*forced failure"):
+            mm.computeFlowBatch(*ims)
+        for a, b in zip(mm.computeFlowBatch(*ims), exp):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        mm.close()
+        ref.close()
+    # without the test switch a repeated device is refused
+    monkeypatch.delenv("B2F_MULTI_ALLOW_DUPLICATE")
+    with pytest.raises(Exception, match="listed twice|exceeds the visible devices"):
+        back2future.MultiModel("random:soft:5:2.0", n_gpus=2, devices=[0, 0])
+
+
 def test_multi_gpu_entry_point_on_the_visible_gpus(monkeypatch):
     """b2f_init_multi / b2f_multi_compute_flow_batch on every visible GPU (one on the test box): the sharded batch must
     equal the single-context results bit for bit, and every replica must hold replica 0's weights.  With one GPU the

@@ -9,11 +9,11 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b2f -- \
-  python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > $OUT/bench_under_rocprof.log 2>&1
+  python3 $R/bench.py --steps 5 --warmup 2 --no-extras > $OUT/bench_under_rocprof.log 2>&1
 echo "stats rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o b2f -- \
-    python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/pmc_$c.log 2>&1
+    python3 $R/bench.py --steps 1 --warmup 1 --no-extras > $OUT/pmc_$c.log 2>&1
   echo "$c rc=$?"
 done
 cd $R

@@ -13,6 +13,6 @@ i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   timeout 240 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -o b2f -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 16 --no-cpu-baseline --no-host-path > $OUT.pass$i.log 2>&1
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --batch 16 --no-extras > $OUT.pass$i.log 2>&1
   echo "pass$i rc=$?"
 done

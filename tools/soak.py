@@ -20,8 +20,9 @@ def main():
     maxh = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     maxw = int(sys.argv[4]) if len(sys.argv) > 4 else 420
     maxn = int(sys.argv[5]) if len(sys.argv) > 5 else 6
-    os.environ["B2F_WINO4_MIN_PIXELS"] = "4096"      # kernel choice independent of the batch: bit-identical results
     models = {"hard": back2future.Model("random:hard:3:2.0"), "soft": back2future.Model("random:soft:3:2.0")}
+    for m in models.values():
+        m.set_option("wino4_min_pixels", 4096)       # kernel choice independent of the batch: bit-identical results (the default)
     free0 = None
     t0 = time.time()
     for it in range(iters):
@@ -30,8 +31,10 @@ def main():
         n = int(r.integers(1, maxn + 1))
         kind = int(r.integers(3))                   # 0 floats, 1 k/255 floats, 2 bytes
         pinned = bool(r.integers(2))
-        os.environ["B2F_HOST_SUBBATCH_PIXELS"] = str(int(r.choice([H0 * W0, 3 * H0 * W0, 1 << 22, 1 << 24])))
-        os.environ["B2F_HOST_THREADS"] = str(int(r.choice([2, 5, 16])))
+        # options live in the context (the environment only seeds them in b2f_init): set them per iteration through the API
+        sub_px, thr = int(r.choice([H0 * W0, 3 * H0 * W0, 1 << 22, 1 << 24])), int(r.choice([2, 5, 16]))
+        m.set_option("host_subbatch_pixels", sub_px)
+        m.set_option("host_threads", thr)
         m.set_option("host_graph", int(r.integers(2)))
         by = r.integers(0, 256, (3, n, 3, H0, W0), dtype=np.uint8)
         if kind == 2:
@@ -53,7 +56,7 @@ def main():
                 print("MISMATCH it %d %dx%d n=%d kind=%d pinned=%d triplet %d: max|dflow| %.3g at %s (%d values differ), masks differ %d / %d; env %s graph %s"
                       % (it, H0, W0, n, kind, pinned, i, d.max(), np.unravel_index(d.argmax(), d.shape), int((d > 0).sum()),
                          int((fo1[0] != fo[i]).sum()), int((bo1[0] != bo[i]).sum()),
-                         {k: v for k, v in os.environ.items() if k.startswith("B2F_")}, "?"), flush=True)
+                         {"host_subbatch_pixels": sub_px, "host_threads": thr}, m.get_option("host_graph")), flush=True)
                 again = m.computeFlowBatch(*ims)
                 print("   batch recomputed equals first batch result:", np.array_equal(again[0], flow), " single recomputed equals single:",
                       np.array_equal(m.computeFlowBatch(*one)[0], f1), flush=True)
