@@ -28,6 +28,7 @@ SIGNATURES = {
     "b2f_weights_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     "b2f_commit_weights": (C.c_int, [C.c_void_p]),
     "b2f_load_t7": (C.c_int, [C.c_char_p, c_float_p, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "b2f_load_t7_ex": (C.c_int, [C.c_char_p, C.c_char_p, c_float_p, C.c_longlong, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]),
     "b2f_compute_flow": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int,
                                    C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)]),
     "b2f_compute_flow_batch": (C.c_int, [C.c_void_p, C.c_int, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int,

@@ -621,6 +621,28 @@ int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *
 }
 B2F_CATCH("b2f_load_t7")
 
+int b2f_load_t7_ex(const char *path, const char *graph_opts, float *out, long long cap, long long *n, char *opts_out, int opts_cap) try
+{
+    if (!path) return fail("b2f_load_t7_ex: null path");
+    GraphOpts g;
+    std::string err;
+    if (!parse_graph_opts(graph_opts, g, err)) return fail("b2f_load_t7_ex: " + err);
+    std::vector<float> flat;
+    if (!load_t7_ex(path, g, !(graph_opts && *graph_opts), flat, err)) return fail("b2f_load_t7_ex: " + err);
+    if (n) *n = (long long)flat.size();
+    if (opts_out && opts_cap > 0) {
+        const std::string t = graph_opts_string(g);
+        if ((int)t.size() + 1 > opts_cap) return fail("b2f_load_t7_ex: option buffer too small");
+        memcpy(opts_out, t.c_str(), t.size() + 1);
+    }
+    if (out) {
+        if (cap < (long long)flat.size()) return fail("b2f_load_t7_ex: output buffer too small");
+        memcpy(out, flat.data(), flat.size() * sizeof(float));
+    }
+    return 0;
+}
+B2F_CATCH("b2f_load_t7_ex")
+
 int b2f_init(const char *name_or_path, int device, b2f_ctx **out) { return b2f_init_ex(name_or_path, device, nullptr, out); }
 
 int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2f_ctx **out) try
@@ -652,9 +674,10 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         else if (path == "Ours-Soft-ft-KITTI") path = "models/RoamingImages_H_KITTI_S.t7";   // :104-106
         else if (path == "Ours-Soft-ft-Sintel") path = "models/RoamingImages_H_Sintel_S.t7"; // :108-110
         if (ends_with(path, ".t7")) {
+            // without graph options the shape (win, levels, skip) is read from the file; with them the file must be that graph
             std::string err;
-            if (!g.shipped()) return fail("b2f_init: graph options other than the shipped ones are read from random: / .b2fw weights only");
-            if (!load_t7(path, flat, past, err)) return fail("b2f_init: " + err);
+            if (!load_t7_ex(path, g, !(graph_opts && *graph_opts), flat, err)) return fail("b2f_init: " + err);
+            past = g.past_flow;
         } else if (ends_with(path, ".b2fw")) {
             FILE *f = fopen(path.c_str(), "rb");
             if (!f) return fail("b2f_init: cannot open " + path);

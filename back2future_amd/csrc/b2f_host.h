@@ -62,5 +62,7 @@ void random_weights(unsigned long long seed, bool past_flow, float gain, float *
 
 // .t7 reader (b2f_t7.cpp): returns false and fills err on failure.
 bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow, std::string &err);
+// any graph shape: infer = true takes win / levels / skip from the file, false checks the file against g (see b2f_t7.cpp)
+bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<float> &flat, std::string &err);
 
 }  // namespace b2f

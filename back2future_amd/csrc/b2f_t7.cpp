@@ -294,7 +294,12 @@ int mulconstant_signs(const Ref &node, int depth)
 
 }  // namespace
 
-bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow, std::string &err)
+// Reads a model file into the canonical flat order of graph `g`.  infer = true: the graph shape is taken from the file -- win
+// from the nn.CostVolMulti nodes' `win` field (CostVolMulti.lua:26-37), levels from the convUnits present, skip (pwc_skip) from
+// the coarsest .. finest decoder levels found (pwc.lua:136,237), the remaining createModelMulti options at their defaults; infer =
+// false: the file must BE graph `g` (same win, same units; the decoders' input widths are matched against g's, so two_frame /
+// pwc_sum_cvs / occ_input files are told from the default wiring).  g.past_flow is set from the file either way.
+bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<float> &flat, std::string &err)
 {
     Reader R;
     R.f = fopen(path.c_str(), "rb");
@@ -303,18 +308,30 @@ bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow,
     fclose(R.f);
     if (!R.ok) { err = "'" + path + "' is not a readable binary .t7 file: " + R.err; return false; }
     std::set<const Obj *> visited;
-    Ref g = find_gmodule(root, visited);   // unwraps nn.DataParallelTable, back2future.lua:114-116
-    if (!g) { err = "no nn.gModule found in '" + path + "'"; return false; }
-    std::vector<Ref> nodes = array_of(field(g, "forwardnodes"));
+    Ref gm = find_gmodule(root, visited);   // unwraps nn.DataParallelTable, back2future.lua:114-116
+    if (!gm) { err = "no nn.gModule found in '" + path + "'"; return false; }
+    std::vector<Ref> nodes = array_of(field(gm, "forwardnodes"));
     if (nodes.empty()) { err = "gModule has no forwardnodes"; return false; }
 
     static const int kLevelOfFeatIn[8] = {0, 0, 3, 16, 32, 64, 96, 128};   // nInputPlane of convUnit l
+    struct Dec {
+        int n, kind;
+        std::vector<ConvW> convs;
+    };
     std::map<int, std::vector<ConvW>> feat;                               // level -> 2 convs
-    std::map<std::pair<int, int>, std::vector<ConvW>> dec;                // (level, kind) -> 6 convs
+    std::vector<Dec> decs;
     std::set<const Obj *> seen_seq;
+    int file_win = 0;
     for (const Ref &node : nodes) {
         Ref data = field(node, "data");
         Ref mod = data ? field(data, "module") : nullptr;
+        if (mod && class_is(mod, "nn.CostVolMulti")) {
+            Ref wn = field(mod, "win");
+            if (wn && wn->num > 0) {
+                if (file_win && file_win != (int)wn->num) { err = "CostVolMulti nodes with different windows"; return false; }
+                file_win = (int)wn->num;
+            }
+        }
         if (!mod || !class_is(mod, "nn.Sequential") || seen_seq.count(mod.get())) continue;
         seen_seq.insert(mod.get());
         std::vector<ConvW> convs;
@@ -331,32 +348,57 @@ bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow,
             if (!level) { err = "unexpected convUnit shape"; return false; }
             if (!feat.count(level)) feat[level] = std::move(convs);   // the three siamese clones share weights
         } else if (convs.size() == 6) {
-            const int n = convs[0].ci;
-            int level = 0;
-            for (int l = 3; l <= 7; ++l)
-                if (n == kNDh + kFeatH[l] + 2 || (l == 7 && (n == kNDh || n == kNDh + kFeatH[7]))) level = l;
-            if (!level) { err = "unexpected decoder input width " + std::to_string(n); return false; }
-            int kind;
+            Dec d;
+            d.n = convs[0].ci;
             bool to_softmax = false;
             for (const Ref &ch : array_of(field(node, "children"))) {
                 Ref d2 = field(ch, "data");
                 Ref m2 = d2 ? field(d2, "module") : nullptr;
                 if (m2 && class_is(m2, "SpatialSoftMax")) to_softmax = true;
             }
-            if (to_softmax) kind = KIND_OCC;
-            else kind = (mulconstant_signs(node, 0) & 1) ? KIND_FLOW : KIND_PAST;
-            if (dec.count({level, kind})) { err = "two decoders with the same role at level " + std::to_string(level); return false; }
-            dec[{level, kind}] = std::move(convs);
+            if (to_softmax) d.kind = KIND_OCC;
+            else d.kind = (mulconstant_signs(node, 0) & 1) ? KIND_FLOW : KIND_PAST;
+            d.convs = std::move(convs);
+            decs.push_back(std::move(d));
         }
     }
-    past_flow = false;
+    if (feat.empty() || decs.empty()) { err = "no convUnit / decoder found in the graph"; return false; }
+    if (infer) {
+        g = GraphOpts();
+        if (file_win) g.win = file_win;
+        g.levels = feat.rbegin()->first;
+    } else if (file_win && file_win != g.win) {
+        err = "the file's cost volumes use a " + std::to_string(file_win) + "-wide window, the graph options say " + std::to_string(g.win);
+        return false;
+    }
+    if (feat.rbegin()->first != g.levels) { err = "the file has " + std::to_string(feat.rbegin()->first) + " pyramid levels, the graph options say " + std::to_string(g.levels); return false; }
+    // decoder level = the level whose first-layer width for that role is the decoder's (widths differ per level: pwc.lua:288-337)
+    std::map<std::pair<int, int>, std::vector<ConvW>> dec;                // (level, kind) -> 6 convs
+    int lmin = 8;
+    for (Dec &d : decs) {
+        int level = 0;
+        for (int l = 2; l <= g.levels; ++l)
+            if (d.n == (d.kind == KIND_OCC ? g.occ_in(l) : g.flow_in(l))) {
+                if (level) { err = "decoder input width " + std::to_string(d.n) + " fits two levels"; return false; }
+                level = l;
+            }
+        if (!level) { err = "unexpected decoder input width " + std::to_string(d.n) + " (window / two_frame / pwc_sum_cvs / occ_input of the file differ from the graph options?)"; return false; }
+        if (dec.count({level, d.kind})) { err = "two decoders with the same role at level " + std::to_string(level); return false; }
+        dec[{level, d.kind}] = std::move(d.convs);
+        lmin = std::min(lmin, level);
+    }
+    if (infer) g.skip = lmin - 1;
+    else if (lmin != g.l_st()) { err = "the file's finest decoder level is " + std::to_string(lmin) + ", the graph options say " + std::to_string(g.l_st()); return false; }
+    bool past_flow = false;
     for (auto &kv : dec)
         if (kv.first.second == KIND_PAST) past_flow = true;
-    Ref pf = field(g, "past_flow");   // model.past_flow, pwc.lua:494
+    Ref pf = field(gm, "past_flow");   // model.past_flow, pwc.lua:494
     if (pf && pf->kind == Obj::BOOL && pf->b != past_flow) { err = "past_flow field disagrees with the graph"; return false; }
+    g.past_flow = past_flow;
+    if (!g.valid()) { err = "the file's graph shape is outside what this library runs: " + graph_opts_string(g); return false; }
 
     long long total = 0;
-    const std::vector<ConvDesc> lay = weight_layout(past_flow, &total);
+    const std::vector<ConvDesc> lay = weight_layout(g, &total);
     flat.assign((size_t)total, 0.f);
     for (const ConvDesc &d : lay) {
         const ConvW *src = nullptr;
@@ -372,6 +414,15 @@ bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow,
         memcpy(flat.data() + d.w_off, src->w.data(), src->w.size() * sizeof(float));
         memcpy(flat.data() + d.b_off, src->b.data(), src->b.size() * sizeof(float));
     }
+    return true;
+}
+
+// the shipped graph shape (win 9, levels 7, skip 2), as back2future.lua:97-113 loads it
+bool load_t7(const std::string &path, std::vector<float> &flat, bool &past_flow, std::string &err)
+{
+    GraphOpts g;
+    if (!load_t7_ex(path, g, false, flat, err)) return false;
+    past_flow = g.past_flow;
     return true;
 }
 

@@ -61,8 +61,11 @@ B2F_API int b2f_init(const char *name_or_path, int device, b2f_ctx **out);
 /* Same with the graph shape of createModelMulti(opt) (models/pwc.lua:88-121) given explicitly, for models other
  * than the shipped ones: graph_opts = "win=5,levels=4" (createModelMulti(nil), pwc.lua:88), or any subset of
  * win (pwc_ws), levels, skip (pwc_skip, >= 1), two_frame, sum_cvs (pwc_sum_cvs), residual, occ_input,
- * rescale_flow, flownet_factor; NULL / "" = the shipped graph (opts.lua:83-98).  frames = 3 and pwc_siamese = 1
- * are fixed.  Weights: "random:hard|soft[:seed[:gain]]" or a .b2fw blob in the canonical order of that graph
+ * rescale_flow, flownet_factor; NULL / "" = the shipped graph (opts.lua:83-98) -- or, for a ".t7" file, whatever
+ * shape the file holds: win is read from its nn.CostVolMulti nodes (CostVolMulti.lua:26-37), levels and skip from the
+ * convUnits / decoders in its node list (pwc.lua:136,237), the other options stay at their defaults; with graph_opts
+ * given the file must be that graph.  frames = 3 and pwc_siamese = 1
+ * are fixed.  Weights: "random:hard|soft[:seed[:gain]]", a ".t7" file or a .b2fw blob in the canonical order of that graph
  * (feature units l = 2..levels, then l = levels..skip+1 {occ, flow, [past-flow] decoder}).  Non-shipped shapes run
  * on a generic, untuned executor (every Lua node its own kernels); H and W of b2f_forward must then be multiples
  * of 2^(levels-1), computeFlow keeps the reference's /64 rounding.                                            */
@@ -94,6 +97,11 @@ B2F_API int b2f_commit_weights(b2f_ctx *ctx);
 /* Host-only .t7 reader (replaces torch.load + nngraph walk): fills out[n] in canonical
  * order and sets *past_flow.  No GPU needed.                                       */
 B2F_API int b2f_load_t7(const char *path, float *out, long long cap, long long *n, int *past_flow);
+/* The same for any graph shape (torch.load of a model built by createModelMulti(opt), pwc.lua:88-121): graph_opts NULL / "" =
+ * read win / levels / skip from the file, else the file must be that graph; opts_out (optional, opts_cap bytes) receives the
+ * graph as an option string ("win=5,levels=4,skip=2,...,past_flow=1"), out[n] the weights in that graph's canonical order. */
+B2F_API int b2f_load_t7_ex(const char *path, const char *graph_opts, float *out, long long cap, long long *n, char *opts_out,
+                   int opts_cap);
 
 /* ---- the hot path, host boundary: computeFlow (back2future.lua:47-95) ----
  * im1..im3: 3 x H0 x W0 planar RGB floats in [0,1] (what image.load returns).

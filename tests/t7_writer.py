@@ -135,11 +135,14 @@ def _conv(cls_prefix, tcls, scls, w, b, stride, share=None):
     return m, (ws, bs, gws, gbs)
 
 
-def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False):
-    """The object tree torch.save(model) would produce for createModelMulti(opt) with the shipped
-    options (pwc.lua:87-508).  Only what the reader may look at is faithful: node/module classes,
-    children links, Sequential contents, tensor sharing, MulConstant constants, model fields."""
-    v = W.views(np.asarray(flat, np.float32), past_flow)
+def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False, o=None):
+    """The object tree torch.save(model) would produce for createModelMulti(opt) (pwc.lua:87-508) -- the shipped options, or with
+    `o` (weights.graph_opts) another window / number of levels / pwc_skip (the other options at their defaults).  Only what
+    the reader may look at is faithful: node/module classes, children links, Sequential contents, tensor sharing, MulConstant
+    constants, the CostVolMulti nodes' win field, model fields."""
+    o = o or W.SHIPPED
+    LV, SK, WIN = o["levels"], o["skip"], o["win"]
+    v = W.views(np.asarray(flat, np.float32), past_flow, o)
     tcls = "torch.CudaTensor" if cuda else "torch.FloatTensor"
     scls = "torch.CudaStorage" if cuda else "torch.FloatStorage"
     cp = "cudnn" if cudnn else "nn"
@@ -163,13 +166,13 @@ def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False):
     ds = {}
     for f in (1, 3):
         ds[f] = {1: Is[f]}
-        for l in range(2, 6):
+        for l in range(2, LV - SK + 1):
             ds[f][l] = node(TorchObj(cp + ".SpatialAveragePooling", kW=2, kH=2, dW=2, dH=2), ds[f][l - 1])
     # siamese feature towers: frames 2 and 3 are clones sharing the storages of frame 1 (pwc.lua:187-195)
     cs, shares = {}, {}
     for f in (1, 2, 3):
         cs[f] = {1: Is[f]}
-        for l in range(2, 8):
+        for l in range(2, LV + 1):
             c1, s1 = _conv(cp, tcls, scls, v["feat%d.conv1.w" % l], v["feat%d.conv1.b" % l], 2, shares.get((l, 1)))
             c2, s2 = _conv(cp, tcls, scls, v["feat%d.conv2.w" % l], v["feat%d.conv2.b" % l], 1, shares.get((l, 2)))
             shares[(l, 1)], shares[(l, 2)] = s1, s2
@@ -195,38 +198,44 @@ def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False):
     mulc = lambda p, k: node(TorchObj("nn.MulConstant", constant_scalar=float(k), inplace=False), p)
     ws = {1: {}, 3: {}}
     ufs, ubfs, outs = {}, {}, {}
-    for l in range(7, 2, -1):
-        src = cs if l == 7 else ws
-        cvf = node(TorchObj("nn.CostVolMulti", win=9, fwd=True, verbose=False), cs[2][l], src[3][l])
-        cvb = node(TorchObj("nn.CostVolMulti", win=9, fwd=False, verbose=False), cs[2][l], src[1][l])
+    for l in range(LV, SK, -1):
+        src = cs if l == LV else ws
+        cvf = node(TorchObj("nn.CostVolMulti", win=WIN, fwd=True, verbose=False), cs[2][l], src[3][l])
+        cvb = node(TorchObj("nn.CostVolMulti", win=WIN, fwd=False, verbose=False), cs[2][l], src[1][l])
         cv = node(TorchObj("nn.JoinTable", dimension=2), cvf, cvb)
-        oin = [cv, cs[2][l]] + ([ufs[l + 1]] if l != 7 else [])
+        oin = [cv, cs[2][l]] + ([ufs[l + 1]] if l != LV else [])
         occ = node(TorchObj(cp + ".SpatialSoftMax"), node(decoder(l, "occ"), node(TorchObj("nn.JoinTable", dimension=2), *oin)))
-        skip_occ = nn2(nn2(occ))
-        if l == 7:
+        skip_occ = occ
+        for _ in range(SK):
+            skip_occ = nn2(skip_occ)
+        if l == LV:
             fs = node(decoder(l, "flow"), cv)
             bfs = node(decoder(l, "past"), cv) if past_flow else None
         else:
             fs = node(decoder(l, "flow"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ufs[l + 1]))
             bfs = node(decoder(l, "past"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ubfs[l + 1])) if past_flow else None
         ufs[l] = up(fs)
-        skip_u = up(ufs[l])
+        skip_u = ufs[l]
+        for _ in range(SK - 1):
+            skip_u = up(skip_u)
         if past_flow:
             ubfs[l] = up(bfs)
-            skip_ub = up(ubfs[l])
+            skip_ub = ubfs[l]
+            for _ in range(SK - 1):
+                skip_ub = up(skip_ub)
         iws = {}
         for f in (1, 3):
-            if l > 3:
+            if l > SK + 1:
                 ws[f][l - 1] = warp(cs[f][l - 1], mulc(ufs[l], 20.0 * (f - 2) / 2 ** (l - 2)))
             tmp = skip_ub if (past_flow and f < 2) else skip_u
-            iws[f] = warp(ds[f][l - 2], mulc(tmp, 20.0 * (f - 2) / 2 ** (l - 3)))
+            iws[f] = warp(ds[f][l - SK], mulc(tmp, 20.0 * (f - 2) / 2 ** (l - SK - 1)))
         outs[l] = [skip_u] + ([skip_ub] if past_flow else []) + [skip_occ, iws[1], iws[3]]
-    out_nodes = [n for l in range(3, 8) for n in outs[l]]
+    out_nodes = [n for l in range(SK + 1, LV + 1) for n in outs[l]]
     outnode = node(TorchObj("nn.Identity"), *out_nodes)
     modules = [n.fields["data"]["module"] for n in nodes]
     g = TorchObj("nn.gModule", forwardnodes=nodes, modules=modules, outnode=outnode, innode=inp,
                  nInputs=1, verbose=False, train=False, past_flow=bool(past_flow),
-                 flow_scale=[20.0 / 2 ** (l - 3) for l in range(7, 2, -1)])
+                 flow_scale=[20.0 / 2 ** (l - SK - 1) for l in range(LV, SK, -1)])
     if dpt:
         g = TorchObj("nn.DataParallelTable", modules=[g], gpuAssignments=[1], dimension=1, train=False)
     return g

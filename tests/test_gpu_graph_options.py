@@ -79,3 +79,28 @@ def test_shipped_graph_is_unaffected_by_an_empty_option_string():
     finally:
         a.close()
         b.close()
+
+
+def test_non_shipped_graph_from_a_t7_file(tmp_path):
+    """b2f_init on a .t7 that holds createModelMulti(nil) (win 5, levels 4): the graph shape comes out of the file (no option
+    string), the context computes what the same weights give through the option-string route, bit for bit."""
+    from tests import t7_writer
+    o = W.graph_opts(win=5, levels=4)
+    flat = W.random_init(3, True, 2.0, o)
+    p = str(tmp_path / "nil.t7")
+    with open(p, "wb") as f:
+        t7_writer.Writer(f).obj(t7_writer.build_model(flat, True, o=o))
+    a = back2future.Model(p)
+    b = back2future.Model("random:soft:3:2.0", graph=W.opts_string(o))
+    try:
+        assert (a.levels, a.win, a.past_flow) == (4, 5, True)
+        np.testing.assert_array_equal(a.get_weights(), flat)
+        rng = np.random.default_rng(9)
+        ims = [rng.random((3, 128, 192), dtype=np.float32) for _ in range(3)]
+        for u, v in zip(a.computeFlow(*ims), b.computeFlow(*ims)):
+            np.testing.assert_array_equal(u, v)
+        with pytest.raises(Exception, match="window"):
+            back2future.Model(p, graph="win=9,levels=4")
+    finally:
+        a.close()
+        b.close()

@@ -90,3 +90,43 @@ def test_function_tags_are_framed_independently(tmp_path):
                "model": t7_writer.build_model(W.random_init(2, False, 1.0), False, cuda=False)})
     got, pf = load_t7(str(p))
     np.testing.assert_array_equal(got, W.random_init(2, False, 1.0))
+
+
+def load_t7_ex(path, graph=None):
+    L = _lib.lib()
+    n = C.c_longlong()
+    opts = C.create_string_buffer(256)
+    g = graph.encode() if graph is not None else None
+    _lib.check(L.b2f_load_t7_ex(path.encode(), g, None, 0, C.byref(n), opts, 256))
+    out = np.empty(n.value, np.float32)
+    _lib.check(L.b2f_load_t7_ex(path.encode(), g, _lib.fptr(out), out.size, C.byref(n), opts, 256))
+    return out, dict(kv.split("=") for kv in opts.value.decode().split(","))
+
+
+@pytest.mark.parametrize("win,levels,skip,past", [(5, 4, 2, True), (7, 5, 1, False), (3, 6, 3, True), (9, 7, 2, False)])
+def test_other_graph_shapes_are_read_from_the_file(tmp_path, win, levels, skip, past):
+    """createModelMulti(opt) with another window / number of levels / pwc_skip saved as .t7: the reader takes win from the
+    nn.CostVolMulti nodes' win field (CostVolMulti.lua:26-37), levels from the convUnits and skip from the decoder levels in the
+    node list (pwc.lua:136,237) and returns the weights in THAT graph's canonical order."""
+    o = W.graph_opts(win=win, levels=levels, skip=skip)
+    flat = W.random_init(17, past, 1.0, o)
+    p = str(tmp_path / "m.t7")
+    with open(p, "wb") as f:
+        t7_writer.Writer(f).obj(t7_writer.build_model(flat, past, cuda=False, cudnn=False, o=o))
+    got, opts = load_t7_ex(p)
+    assert (int(opts["win"]), int(opts["levels"]), int(opts["skip"]), int(opts["past_flow"])) == (win, levels, skip, int(past))
+    np.testing.assert_array_equal(got, flat)
+    # given explicitly, the options must describe the file
+    got2, _ = load_t7_ex(p, "win=%d,levels=%d,skip=%d" % (win, levels, skip))
+    np.testing.assert_array_equal(got2, flat)
+    with pytest.raises(_lib.B2FError, match="window|levels|decoder"):
+        load_t7_ex(p, "win=%d,levels=%d,skip=%d" % (win + 2 if win < 13 else 3, levels, skip))
+    if levels > 2:
+        with pytest.raises(_lib.B2FError, match="levels"):
+            load_t7_ex(p, "win=%d,levels=%d,skip=%d" % (win, levels - 1, min(skip, levels - 2)))
+    # b2f_load_t7 (no options) stays the loader of the shipped shape
+    if (win, levels, skip) == (9, 7, 2):
+        np.testing.assert_array_equal(load_t7(p)[0], flat)
+    else:
+        with pytest.raises(_lib.B2FError):
+            load_t7(p)
