@@ -271,6 +271,13 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
 }
 
 }  // namespace
+void b2f::drop_gen_out(b2f_ctx *c)
+{
+    for (float *p : c->gen_out)
+        if (p) (void)hipFree(p);
+    c->gen_out.clear();
+    c->genB = c->genH = c->genW = 0;
+}
 void b2f::drop_graphs(b2f_ctx *c)
 {
     for (auto &g : c->graphs)
@@ -575,6 +582,7 @@ int install_weights(b2f_ctx *c, const float *flat, long long n, bool past)
     // captured graphs hold the packed-weight pointers and the Hard / Soft topology of the moment they were captured
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(c);
+    drop_gen_out(c);
     if (c->w_dev && (c->nparams != n)) { HIPCHK(hipFree(c->w_dev)); c->w_dev = nullptr; }
     c->past_flow = past;
     c->g = g;
@@ -747,6 +755,7 @@ void b2f_destroy(b2f_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graphs(c);
+    drop_gen_out(c);
     for (ProfEvent &pe : c->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (HostSlot &hs : c->slot) {
@@ -930,21 +939,29 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
         // other graph shapes: the whole output table through the generic executor (b2f_graph.hip), then est[1] / the
         // finest occlusion map / est[3] into the caller's buffers.  Synchronous, no hipGraph: a correctness path.
         const int n = c->g.n_outputs(), per = c->past_flow ? 5 : 4, lst = c->g.l_st();
-        std::vector<float *> dev((size_t)n, nullptr);
-        int rc = 0;
-        for (int i = 0; i < n && !rc; ++i) {
-            const int l = lst + i / per, j = i % per;
-            const size_t cnt = (size_t)B * (H >> (l - lst)) * (W >> (l - lst)) * ((j >= per - 2) ? 3 : 2);
-            if (hipMalloc(&dev[(size_t)i], cnt * sizeof(float)) != hipSuccess) rc = fail("b2f_forward_device: out of device memory");
+        // the output table lives in the context and is re-allocated only when the shape changes (a hipMalloc / hipFree pair per
+        // call is device-synchronising and stalled the upload / download overlap of the host pipeline: ADVICE r2)
+        if ((int)c->gen_out.size() != n || c->genB != B || c->genH != H || c->genW != W) {
+            HIPCHK(hipDeviceSynchronize());
+            drop_gen_out(c);
+            c->gen_out.assign((size_t)n, nullptr);
+            for (int i = 0; i < n; ++i) {
+                const int l = lst + i / per, j = i % per;
+                const size_t cnt = (size_t)B * (H >> (l - lst)) * (W >> (l - lst)) * ((j >= per - 2) ? 3 : 2);
+                if (hipMalloc(&c->gen_out[(size_t)i], cnt * sizeof(float)) != hipSuccess) {
+                    drop_gen_out(c);
+                    return fail("b2f_forward_device: out of device memory");
+                }
+            }
+            c->genB = B; c->genH = H; c->genW = W;
         }
-        if (!rc) rc = graph_forward(c, s, false, dev_in, in_kind, B, H, W, dev.data());
+        std::vector<float *> &dev = c->gen_out;
+        CHK(graph_forward(c, s, false, dev_in, in_kind, B, H, W, dev.data()));
         const size_t n2 = (size_t)B * 2 * H * W * sizeof(float);
-        if (!rc && dev_flow && hipMemcpyAsync(dev_flow, dev[0], n2, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
-        if (!rc && dev_occ && hipMemcpyAsync(dev_occ, dev[(size_t)(c->past_flow ? 2 : 1)], n2, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
-        if (!rc && dev_est3 && hipMemcpyAsync(dev_est3, dev[2], c->past_flow ? n2 : n2 / 2 * 3, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("b2f_forward_device: copy failed");
-        if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail("b2f_forward_device: synchronize failed");
-        for (float *p : dev) if (p) (void)hipFree(p);
-        return rc;
+        if (dev_flow) HIPCHK(hipMemcpyAsync(dev_flow, dev[0], n2, hipMemcpyDeviceToDevice, s));
+        if (dev_occ) HIPCHK(hipMemcpyAsync(dev_occ, dev[(size_t)(c->past_flow ? 2 : 1)], n2, hipMemcpyDeviceToDevice, s));
+        if (dev_est3) HIPCHK(hipMemcpyAsync(dev_est3, dev[2], c->past_flow ? n2 : n2 / 2 * 3, hipMemcpyDeviceToDevice, s));
+        return 0;
     }
     const Plan P = make_plan(B, H, W, false, c->past_flow);
     CHK(ensure_workspace(c, P));

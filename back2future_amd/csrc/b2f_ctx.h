@@ -231,6 +231,9 @@ struct b2f_ctx {
     int host_u8 = 1, host_ramp = 1;
     int debug_fail_next = 0;       // tests: the next b2f_compute_flow* call on this context fails (cross-thread error hand-over of b2f_multi_*)
     std::map<b2f::GraphKey, hipGraphExec_t> graphs;
+    // output table of the generic executor (non-shipped graph shapes), kept between calls of one (B, H, W)
+    std::vector<float *> gen_out;
+    int genB = 0, genH = 0, genW = 0;
     // profiling
     std::vector<std::string> prof_names;
     std::vector<double> prof_ms;
@@ -263,6 +266,7 @@ namespace b2f {
 // b2f_api.hip
 int check_shape(int B, int H, int W);
 void drop_graphs(b2f_ctx *c);
+void drop_gen_out(b2f_ctx *c);
 // model:forward on device pointers, optionally replayed from a hipGraph (see b2f_api.hip)
 int forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H, int W, float *dev_flow, float *dev_occ,
                    float *dev_est3, hipStream_t s, bool graph);
