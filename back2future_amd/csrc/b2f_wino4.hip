@@ -258,93 +258,96 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         _Pragma("unroll") for (int i = 0; i < 3; ++i) if (s_ok[i]) r[s_slot[i]] = sr[i];            \
     } while (0)
 
-    // ---- input transform role: thread = (tile t = lane & 31, k4 = lane >> 5, row a = wave; waves 6, 7 redo
-    // row 5 and drop the result, so that all waves run the same instruction stream) ----
-    const int ta = wave < 6 ? wave : 5;
-    // row a of B^T as up to four (input row, coefficient) pairs
-    int r0, r1, r2, r3;
-    float c0, c1, c2, c3;
-    switch (ta) {
-    case 0: r0 = 0; r1 = 2; r2 = 4; r3 = 4; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
-    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; c3 = 1.f; break;
-    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
-    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; c3 = 1.f; break;
-    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
-    default: r0 = 1; r1 = 3; r2 = 5; r3 = 5; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+#define W4_MAYBE_CONST const
+    // ---- input transform V = B^T d B of a chunk: thread = (tile t = lane & 31, k4 = lane >> 5, channel pair th = wave & 1 of
+    // the k4 group's four), wave >> 1 selects the rows of B^T d it produces, with the common sub-expressions of the row pairs:
+    //   waves 0, 1: rows 1, 2   P = d4 - 4 d2, Q = d3 - 4 d1, r1 = P + Q,  r2 = P - Q
+    //   waves 2, 3: rows 3, 4   P = d4 -   d2, Q = d3 -   d1, r3 = P + 2Q, r4 = P - 2Q
+    //   waves 4, 5: row 0       P = d4 - 5 d2, Q = d0,        r0 = P + 4Q
+    //   waves 6, 7: row 5       P = d5 - 5 d3, Q = d1,        r5 = P + 4Q
+    // i.e. ONE instruction stream  P = fma(ca, x1, x2), Q = fma(cb, x3, x4), rA = fma(cs, Q, P), rB = fma(-cs, Q, P)  with
+    // wave-uniform rows x1..x4 and coefficients (four packed ops per tile column for two rows, where one row at a time takes
+    // four each), then the 6-point column pass of each produced row (12 packed ops; the single-row waves skip the second).
+    // The waves w and w + 4 of a SIMD carry 48 + 36 packed ops per chunk where the row-per-wave form had 2 x 72 (rows 0..5 on
+    // waves 0..5, waves 6, 7 redoing row 5): fp32 MFMAs and VALU share the issue pipe, so this is time (ablating 44 % of the old
+    // transform's VALU: -4 % on the 200 -> 128 layer, profiles/r03_wino4_notes.txt).
+    const int t_role = wave >> 1;
+    const int th = wave & 1;                                     // channel pair of the float4: x, y | z, w
+    int rx1, rx2, rx3, rx4, t_orow;
+    float t_ca, t_cb, t_cs;
+    switch (t_role) {
+    case 0: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -4.f; t_cb = -4.f; t_cs = 1.f; t_orow = 1; break;
+    case 1: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -1.f; t_cb = -1.f; t_cs = 2.f; t_orow = 3; break;
+    case 2: rx1 = 2; rx2 = 4; rx3 = 0; rx4 = 0; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 0; break;
+    default: rx1 = 3; rx2 = 5; rx3 = 1; rx4 = 1; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 5; break;
     }
+    const bool t_two = t_role < 2;                               // two output rows (t_orow, t_orow + 1)
     const int t_tile = lane & 31, t_k4 = lane >> 5;
     const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
-    const int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
-    const float t_cf[4] = {c0, c1, c2, c3};     // wave-uniform (SGPRs)
-    const int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;        // float4 index of V[xi = 6a][k4][t]; xi+1 -> +64
-    const bool t_write = wave < 6;
-    f32x4 R[6], d[NTV == 1 ? 6 : 3];
-    // slice s = 2 r + h: input row r (of the four), columns 3h .. 3h+2 of the 6-wide tile window
+    W4_MAYBE_CONST int t_row[4] = {t_base + rx1 * RW, t_base + rx2 * RW, t_base + rx3 * RW, t_base + rx4 * RW};
+    W4_MAYBE_CONST int t_dst = (t_orow * 6 * 2 + t_k4) * 32 + t_tile;   // float4 index of V[xi = 6 t_orow][k4][t]; xi+1 -> +64, next row -> +384
+    f32x4 R[6], d[NTV == 1 ? 4 : 2];   // R[j] = (row A of column j | row B); d = (x1 | x2), (x3 | x4) of a column
+    // slice s < 6: column s of the 6-wide tile window (reads of its four rows, then the four packed ops); slice 6 / 7: column
+    // pass + LDS writes of the first / second produced row into V buffer vbuf_
 #define W4_T_READ(s_, rbuf_) W4_T_READ_D(s_, rbuf_, 0)
 #define W4_T_READ_D(s_, rbuf_, db_)                                                                 \
     do {                                                                                            \
-        const f32x4 *rp = Rb + (rbuf_) * RAW_F4 + t_row[(s_) >> 1];                                 \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) d[(db_) + k] = rp[colpos(3 * ((s_) & 1) + k)]; \
+        if ((s_) < 6) {                                                                             \
+            const f32x2 *rp = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4 + colpos(s_)) + th; \
+            const f32x2 x1 = rp[2 * t_row[0]], x2 = rp[2 * t_row[1]], x3 = rp[2 * t_row[2]], x4 = rp[2 * t_row[3]]; \
+            d[(db_)] = __builtin_shufflevector(x1, x2, 0, 1, 2, 3);                                 \
+            d[(db_) + 1] = __builtin_shufflevector(x3, x4, 0, 1, 2, 3);                             \
+        }                                                                                           \
     } while (0)
     // Written as v_pk_* inline asm: hipcc unpacks packed fp32 ops that follow an MFMA into two scalar ones (it
     // assumes they co-issue with the MFMA; behind an fp32 MFMA they do not), and VALU instructions are what
-    // this loop pays for.  The asm also pins the slice here (otherwise instruction selection sinks the fmas to
-    // the column pass and all 24 raw float4 stay live).
-#define W4_T_FMA(s_) W4_T_FMA_D(s_, 0)
-#define W4_T_FMA_D(s_, db_)                                                                         \
+    // this loop pays for.  The asm also pins the slice here.
+#define W4_T_FMA(s_, vbuf_) W4_T_FMA_D(s_, 0, vbuf_)
+#define W4_T_FMA_D(s_, db_, vbuf_)                                                                  \
     do {                                                                                            \
-        const float cf = t_cf[(s_) >> 1];                                                           \
-        const f32x2 cf2 = {cf, cf};                                                                 \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                             \
-            f32x4 &Rk = R[3 * ((s_) & 1) + k];                                                      \
-            const f32x2 dlo = __builtin_shufflevector(d[(db_) + k], d[(db_) + k], 0, 1), dhi = __builtin_shufflevector(d[(db_) + k], d[(db_) + k], 2, 3); \
-            f32x2 lo = __builtin_shufflevector(Rk, Rk, 0, 1), hi = __builtin_shufflevector(Rk, Rk, 2, 3); \
-            if (((s_) >> 1) == 0) {                                                                 \
-                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "s"(cf2), "v"(dlo));            \
-                asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "s"(cf2), "v"(dhi));            \
-            } else {                                                                                \
-                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "s"(cf2), "v"(dlo));        \
-                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "s"(cf2), "v"(dhi));        \
-            }                                                                                       \
-            Rk = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);                                       \
+        if ((s_) < 6) {                                                                             \
+            const f32x2 ca2 = {t_ca, t_ca}, cb2 = {t_cb, t_cb}, cs2 = {t_cs, t_cs}, cn2 = {-t_cs, -t_cs}; \
+            const f32x2 x1 = __builtin_shufflevector(d[(db_)], d[(db_)], 0, 1), x2 = __builtin_shufflevector(d[(db_)], d[(db_)], 2, 3); \
+            const f32x2 x3 = __builtin_shufflevector(d[(db_) + 1], d[(db_) + 1], 0, 1), x4 = __builtin_shufflevector(d[(db_) + 1], d[(db_) + 1], 2, 3); \
+            f32x2 P, Q, oa, ob;                                                                     \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "s"(ca2), "v"(x1), "v"(x2));     \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(Q) : "s"(cb2), "v"(x3), "v"(x4));     \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(oa) : "s"(cs2), "v"(Q), "v"(P));      \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(ob) : "s"(cn2), "v"(Q), "v"(P));      \
+            R[(s_) < 6 ? (s_) : 0] = __builtin_shufflevector(oa, ob, 0, 1, 2, 3);                   \
+        } else if ((s_) == 6) {                                                                     \
+            W4_T_COLPASS(0, (vbuf_));                                                               \
+        } else if (t_two) {                                                                         \
+            W4_T_COLPASS(1, (vbuf_));                                                               \
         }                                                                                           \
     } while (0)
-    // column pass: V[a][.] = R B, then the 6 b128 writes (waves 6, 7 masked)
-#define W4_T_COLS(vbuf_)                                                                            \
+    // column pass of produced row hh_ (0: first, 1: second): V[a][.] = R B (12 packed ops), six 8-byte LDS writes
+#define W4_T_COLPASS(hh_, vbuf_)                                                                    \
     do {                                                                                            \
         const f32x2 k4v = {4.f, 4.f}, k5v = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2v = {2.f, 2.f}, km2 = {-2.f, -2.f}; \
-        f32x4 vo[6];                                                                                \
-        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                          \
-            f32x2 r0 = hh ? __builtin_shufflevector(R[0], R[0], 2, 3) : __builtin_shufflevector(R[0], R[0], 0, 1); \
-            f32x2 r1 = hh ? __builtin_shufflevector(R[1], R[1], 2, 3) : __builtin_shufflevector(R[1], R[1], 0, 1); \
-            f32x2 r2 = hh ? __builtin_shufflevector(R[2], R[2], 2, 3) : __builtin_shufflevector(R[2], R[2], 0, 1); \
-            f32x2 r3 = hh ? __builtin_shufflevector(R[3], R[3], 2, 3) : __builtin_shufflevector(R[3], R[3], 0, 1); \
-            f32x2 r4 = hh ? __builtin_shufflevector(R[4], R[4], 2, 3) : __builtin_shufflevector(R[4], R[4], 0, 1); \
-            f32x2 r5 = hh ? __builtin_shufflevector(R[5], R[5], 2, 3) : __builtin_shufflevector(R[5], R[5], 0, 1); \
-            f32x2 t0, t1, pq, qq, uu, vv, o1, o2, o3, o4;                                           \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "s"(k4v), "v"(r0), "v"(r4));    \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t0) : "s"(k5v), "v"(r2));             \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pq) : "s"(km4), "v"(r2), "v"(r4));    \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(qq) : "s"(km4), "v"(r1), "v"(r3));    \
-            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(uu) : "v"(r4), "v"(r2)); \
-            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(vv) : "v"(r3), "v"(r1)); \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "s"(k4v), "v"(r1), "v"(r5));    \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t1) : "s"(k5v), "v"(r3));             \
-            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o1) : "v"(pq), "v"(qq));                  \
-            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o2) : "v"(pq), "v"(qq)); \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o3) : "s"(k2v), "v"(vv), "v"(uu));    \
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o4) : "s"(km2), "v"(vv), "v"(uu));    \
-            if (hh == 0) {                                                                          \
-                vo[0].xy = t0; vo[1].xy = o1; vo[2].xy = o2; vo[3].xy = o3; vo[4].xy = o4; vo[5].xy = t1; \
-            } else {                                                                                \
-                vo[0].zw = t0; vo[1].zw = o1; vo[2].zw = o2; vo[3].zw = o3; vo[4].zw = o4; vo[5].zw = t1; \
-            }                                                                                       \
-        }                                                                                           \
-        if (t_write) {                                                                              \
-            f32x4 *v = Vb + (vbuf_) * VSTRIDE + t_dst;                                                 \
-            _Pragma("unroll") for (int b = 0; b < 6; ++b) v[64 * b] = vo[b];                        \
-        }                                                                                           \
+        f32x2 r0 = (hh_) ? __builtin_shufflevector(R[0], R[0], 2, 3) : __builtin_shufflevector(R[0], R[0], 0, 1); \
+        f32x2 r1 = (hh_) ? __builtin_shufflevector(R[1], R[1], 2, 3) : __builtin_shufflevector(R[1], R[1], 0, 1); \
+        f32x2 r2 = (hh_) ? __builtin_shufflevector(R[2], R[2], 2, 3) : __builtin_shufflevector(R[2], R[2], 0, 1); \
+        f32x2 r3 = (hh_) ? __builtin_shufflevector(R[3], R[3], 2, 3) : __builtin_shufflevector(R[3], R[3], 0, 1); \
+        f32x2 r4 = (hh_) ? __builtin_shufflevector(R[4], R[4], 2, 3) : __builtin_shufflevector(R[4], R[4], 0, 1); \
+        f32x2 r5 = (hh_) ? __builtin_shufflevector(R[5], R[5], 2, 3) : __builtin_shufflevector(R[5], R[5], 0, 1); \
+        f32x2 t0, t1, pq, qq, uu, vv, o1, o2, o3, o4;                                               \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "s"(k4v), "v"(r0), "v"(r4));        \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t0) : "s"(k5v), "v"(r2));                 \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pq) : "s"(km4), "v"(r2), "v"(r4));        \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(qq) : "s"(km4), "v"(r1), "v"(r3));        \
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(uu) : "v"(r4), "v"(r2)); \
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(vv) : "v"(r3), "v"(r1)); \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "s"(k4v), "v"(r1), "v"(r5));        \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t1) : "s"(k5v), "v"(r3));                 \
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(o1) : "v"(pq), "v"(qq));                      \
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o2) : "v"(pq), "v"(qq)); \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o3) : "s"(k2v), "v"(vv), "v"(uu));        \
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o4) : "s"(km2), "v"(vv), "v"(uu));        \
+        f32x2 *v = reinterpret_cast<f32x2 *>(Vb + (vbuf_) * VSTRIDE + t_dst + 384 * (hh_)) + th;    \
+        v[0] = t0; v[2 * 64] = o1; v[2 * 128] = o2; v[2 * 192] = o3; v[2 * 256] = o4; v[2 * 320] = t1; \
     } while (0)
+#define W4_T_COLS(vbuf_) do {} while (0)      /* (the column passes are slices 6, 7 of W4_T_FMA now) */
 
     if constexpr (NTV == 2) {
     f32x16 acc[9];
@@ -387,10 +390,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s); }
-    W4_T_COLS(0);
-    W4_T_READ(0, 1); W4_T_FMA(0);
-    W4_T_READ(1, 1); W4_T_FMA(1);
+    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s, 0); }
+    W4_T_READ(0, 1); W4_T_FMA(0, 0);
+    W4_T_READ(1, 1); W4_T_FMA(1, 0);
     W4_T_READ(2, 1);
     __syncthreads();
     av[0] = Vb[a_off];
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
             if (x < 6) {                                                                            \
                 /* slice x + 2 of Tr(c+1) (its reads were issued one step ago), then the reads of the next slice */ \
                 if (!(B2F_WINO4_ABLATE & 1)) {                                                      \
-                    W4_T_FMA(x + 2);                                                                \
+                    W4_T_FMA(x + 2, (c + 1) & 1);                                                   \
                     if (x + 3 < 8) W4_T_READ(x + 3, (c + 1) & 1);                                   \
                 }                                                                                   \
             } else if (x == 6) {                                                                    \
@@ -451,9 +453,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
                 if (!(B2F_WINO4_ABLATE & 1)) W4_T_READ(0, c & 1);   /* Tr(c+2), raw(c+2) is in raw buffer c & 1 */ \
                 if (!(B2F_WINO4_ABLATE & 2)) W4_LOAD_RAW(min(c + 3, nchunks - 1));                  \
             } else if (x == 7) {                                                                    \
-                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(0); W4_T_READ(1, c & 1); }                  \
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(0, 0); W4_T_READ(1, c & 1); }               \
             } else {                                                                                \
-                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(1); W4_T_READ(2, c & 1); }                  \
+                if (!(B2F_WINO4_ABLATE & 1)) { W4_T_FMA(1, 0); W4_T_READ(2, c & 1); }               \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (x == 2) W4_T(1);                                                                    \
@@ -574,8 +576,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     }
     __syncthreads();
 #pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2); }
-    W4_T_COLS(0);
+    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2, 0); }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);
@@ -586,15 +587,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
-            if (x < 4) { W4_T_READ_D(2 * x, (c + 1) & 1, 0); W4_T_READ_D(2 * x + 1, (c + 1) & 1, 3); }
+            if (x < 4) { W4_T_READ_D(2 * x, (c + 1) & 1, 0); W4_T_READ_D(2 * x + 1, (c + 1) & 1, 2); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (x < 4 || n == 0)       // the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch)
                     acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (x < 4) { W4_T_FMA_D(2 * x, 0); W4_T_FMA_D(2 * x + 1, 3); }
-            else { W4_T_COLS((c + 1) & 1); W4_WRITE_RAW(c & 1); }
+            if (x < 4) { W4_T_FMA_D(2 * x, 0, (c + 1) & 1); W4_T_FMA_D(2 * x + 1, 2, (c + 1) & 1); }
+            else { W4_WRITE_RAW(c & 1); }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -744,25 +745,23 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         if (s_act) { r[0] = sr[0]; r[6 * RW] = sr[1]; r[12 * RW] = sr[2]; }                         \
     } while (0)
 
-    // ---- input transform role (as in conv3x3_wino4) ----
-    const int ta = wave < 6 ? wave : 5;
-    int r0, r1, r2, r3;
-    float c0, c1, c2, c3;
-    switch (ta) {
-    case 0: r0 = 0; r1 = 2; r2 = 4; r3 = 4; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
-    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; c3 = 1.f; break;
-    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
-    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; c3 = 1.f; break;
-    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
-    default: r0 = 1; r1 = 3; r2 = 5; r3 = 5; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    // ---- input transform role (as in conv3x3_wino4: row pairs with shared sub-expressions, channel pair th = wave & 1) ----
+    const int t_role = wave >> 1;
+    const int th = wave & 1;
+    int rx1, rx2, rx3, rx4, t_orow;
+    float t_ca, t_cb, t_cs;
+    switch (t_role) {
+    case 0: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -4.f; t_cb = -4.f; t_cs = 1.f; t_orow = 1; break;
+    case 1: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -1.f; t_cb = -1.f; t_cs = 2.f; t_orow = 3; break;
+    case 2: rx1 = 2; rx2 = 4; rx3 = 0; rx4 = 0; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 0; break;
+    default: rx1 = 3; rx2 = 5; rx3 = 1; rx4 = 1; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 5; break;
     }
+    const bool t_two = t_role < 2;
     const int t_tile = lane & 31, t_k4 = lane >> 5;
     const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
-    int t_row[4] = {t_base + r0 * RW, t_base + r1 * RW, t_base + r2 * RW, t_base + r3 * RW};
-    const float t_cf[4] = {c0, c1, c2, c3};
-    int t_dst = (ta * 6 * 2 + t_k4) * 32 + t_tile;
-    const bool t_write = wave < 6;
-    f32x4 R[6], d[NTV == 1 ? 6 : 3];
+    int t_row[4] = {t_base + rx1 * RW, t_base + rx2 * RW, t_base + rx3 * RW, t_base + rx4 * RW};
+    int t_dst = (t_orow * 6 * 2 + t_k4) * 32 + t_tile;
+    f32x4 R[6], d[NTV == 1 ? 4 : 2];
 
     if constexpr (NTV == 2) {
     f32x16 acc[9];
@@ -807,8 +806,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s); }
-    W4_T_COLS(0);
+    for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s, 0); }
     __syncthreads();
 
     w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -836,8 +834,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)lz));
             const int lm = ln & 31, lh = ln >> 5, ltid = wave * 64 + ln;
             const int tb = lh * RAW_P + (4 * (lm >> 3)) * RW + (lm & 7);
-            t_row[0] = tb + r0 * RW; t_row[1] = tb + r1 * RW; t_row[2] = tb + r2 * RW; t_row[3] = tb + r3 * RW;
-            t_dst = (ta * 6 * 2 + lh) * 32 + lm;
+            t_row[0] = tb + rx1 * RW; t_row[1] = tb + rx2 * RW; t_row[2] = tb + rx3 * RW; t_row[3] = tb + rx4 * RW;
+            t_dst = (t_orow * 6 * 2 + lh) * 32 + lm;
             a_off = (9 * g * 2 + lh) * 32 + lm;
             b_off = ((9 * g * 2 + lh) * 64 + n * 32 + lm) * 16u;
             const int pix = min(ltid, NSTG - 1) >> 1;
@@ -845,8 +843,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             s_slot = (ltid & 1) * RAW_P + r6 * RW + colpos(px);
             l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (ltid & 1) * 4) * 4u;
         }
-        W4_T_READ(0, par ^ 1); W4_T_FMA(0);
-        W4_T_READ(1, par ^ 1); W4_T_FMA(1);
+        W4_T_READ(0, par ^ 1); W4_T_FMA(0, 0);
+        W4_T_READ(1, par ^ 1); W4_T_FMA(1, 0);
         W4_T_READ(2, par ^ 1);
         av[0] = Vb[par * VSTRIDE + a_off];
         av[1] = Vb[par * VSTRIDE + a_off + 64];
@@ -873,19 +871,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
                 acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[(9 * (PH_) + x) % 6][j], acc[x], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (x < 6) {                                                                            \
-                W4_T_FMA(x + 2);                                                                    \
+                W4_T_FMA(x + 2, pc ^ 1);                                                            \
                 if (x + 3 < 8) W4_T_READ(x + 3, pc ^ 1);                                            \
             } else if (x == 6) {                                                                    \
-                W4_T_COLS(pc ^ 1);                                                                  \
                 W4P_WRITE_RAW(pc);                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 __syncthreads();                                                                    \
                 W4_T_READ(0, pc);                                                                   \
                 if (!(LAST_)) W4P_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
             } else if (x == 7) {                                                                    \
-                W4_T_FMA(0); W4_T_READ(1, pc);                                                      \
+                W4_T_FMA(0, 0); W4_T_READ(1, pc);                                                   \
             } else {                                                                                \
-                W4_T_FMA(1); W4_T_READ(2, pc);                                                      \
+                W4_T_FMA(1, 0); W4_T_READ(2, pc);                                                   \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
@@ -1063,8 +1060,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     }
     __syncthreads();
 #pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2); }
-    W4_T_COLS(0);
+    for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2, 0); }
     __syncthreads();
     for (;;) {
         has_next = v_cur + G < total;
@@ -1086,15 +1082,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
 #pragma unroll
             for (int x = 0; x < 5; ++x) {
-                if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 3); }
+                if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 2); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (x < 4 || n == 0)       // the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch)
                         acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (x < 4) { W4_T_FMA_D(2 * x, 0); W4_T_FMA_D(2 * x + 1, 3); }
-                else { W4_T_COLS(pc ^ 1); W4P_WRITE_RAW(pc); }
+                if (x < 4) { W4_T_FMA_D(2 * x, 0, pc ^ 1); W4_T_FMA_D(2 * x + 1, 2, pc ^ 1); }
+                else { W4P_WRITE_RAW(pc); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
@@ -1226,7 +1222,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
     dim3 grid((unsigned)(tiles * p.nimg * nblk));
     if (p.w4_persist) {
-        // persistent form: one block per CU, worth it from two tiles per block
+        // persistent form
         static int n_cu_dev[64] = {0};                  // per device, like the attribute flags (b2f_init_multi: one worker thread per GPU)
         static bool pattr_done_dev[64] = {false};
         bool &pattr_done = pattr_done_dev[attr_slot()];
@@ -1237,10 +1233,14 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
             n_cu &= ~7;                     // the XCD remap of the virtual block index needs a multiple of 8
             if (n_cu < 8) n_cu = 8;
         }
-        // w4_persist > 1 (tests): persistent form with exactly that many blocks, whatever the launch size
-        const int pgrid = p.w4_persist > 1 ? (p.w4_persist < (int)grid.x ? p.w4_persist : (int)grid.x) : n_cu;
+        // one block per CU (fewer when the launch has fewer tiles); w4_persist > 1 (tests): exactly that many blocks.
+        // Round 3: every launch whose K loop is long enough for the prologue (4 chunks = 32 input channels) runs the persistent
+        // form -- with the row-pair input transform the one-tile two-N-tile kernel no longer fits its 256 registers (22
+        // spills, reloaded behind vmcnt(0)); it remains the path of shallower layers and of wino4_persistent = 0, bit-identical.
+        const int pcap = p.w4_persist > 1 ? p.w4_persist : n_cu;
+        const int pgrid = pcap < (int)grid.x ? pcap : (int)grid.x;
         const int nchunks_p = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
-        if (nchunks_p >= 4 && (p.w4_persist > 1 || (int)grid.x >= 2 * n_cu)) {
+        if (nchunks_p >= 4) {
             if (!pattr_done) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
                 if (e != hipSuccess) return e;

@@ -185,9 +185,9 @@ B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh
  * so a triplet's result never depends on the batch it is computed in; adaptive_kernels = 1
  * picks the variant per launch by block rounds on the 256 CUs instead (faster for single
  * triplets, results then vary at the 1e-6 level with the batch size); corr_variant (-1 auto /
- * 0 .. 4) forces an instantiation of the warp + cost-volume kernel (same bits either way);
- * wino4_persistent (default 1) = F(4x4) launches of at least two tiles per CU run as
- * persistent blocks (0: one tile per block; same bits either way); s2_tiles_per_block
+ * 0 .. 5) forces an instantiation of the warp + cost-volume kernel (same bits either way);
+ * wino4_persistent (default 1) = F(4x4) launches run as persistent blocks, one per CU
+ * (0: one tile per block; same bits either way); s2_tiles_per_block
  * (default 0 = launcher's rule) = tiles a block of the stride-2 kernel chains (same bits).
  * Host pipeline of b2f_compute_flow*: host_subbatch_pixels, host_threads (0 = auto), host_u8,
  * host_ramp.  The library reads no environment variable after b2f_init (which takes
