@@ -859,8 +859,9 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     // ms against 0.060 / 0.081 at batch 16), else by the launch size
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
                   : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 5 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
-    if (variant == 5 && !warp_costvol_unit_supported(p)) variant = 3;
+    if ((variant == 5 || variant == 6) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
+    if (variant == 6) return launch_warp_costvol_spec(p, s);
     if (variant == 4) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_win_kernel<true>), dim3(2 * g2.x), dim3(128), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_win_kernel<false>), dim3(2 * g2.x), dim3(128), 0, s, p);

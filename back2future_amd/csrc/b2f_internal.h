@@ -140,6 +140,8 @@ hipError_t launch_warp_costvol(const CorrLaunch &p, hipStream_t s);
 // b2f_corr5.hip: the persistent "unit" form (variant 5; C a multiple of 32), same bits as the others
 bool warp_costvol_unit_supported(const CorrLaunch &p);
 hipError_t launch_warp_costvol_unit(const CorrLaunch &p, hipStream_t s);
+// the role-specialised form of it (variant 6): FMA waves and gather waves, source window by LDS-DMA
+hipError_t launch_warp_costvol_spec(const CorrLaunch &p, hipStream_t s);
 // generic (any odd win) single-direction cost volume, NHWC in, B x h x w x win*win out
 hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int C, int h, int w,
                                   int win, int fwd, float *out, hipStream_t s);
