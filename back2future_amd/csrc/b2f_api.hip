@@ -137,8 +137,9 @@ int pack_all(b2f_ctx *c, const float *flat)
         p.wino = stride1 ? wino_mode(d.co) : 0;
         if (p.wino == 1 && d.kind != KIND_FEAT && d.idx == 1) p.wino = 0;   // two K segments: not for the narrow kernel
         if (stride1 && use_wino() && d.ci == 16 && d.co == 16) p.wino = 3;  // level-2 convUnit: dedicated kernel
+        if (!stride1 && use_wino() && d.ci == 16 && d.co == 32) p.wino = 5;  // first conv of the level-3 convUnit: dedicated kernel
         if (p.wino == 4) { p.nt = 2; p.nblk = wino4_nblk(d.co); }
-        else if (p.wino == 1 || p.wino == 3) { p.nt = 1; p.nblk = 1; }
+        else if (p.wino == 1 || p.wino == 3 || p.wino == 5) { p.nt = 1; p.nblk = 1; }
         else if (p.wino == 2) wino_choose_tiles(d.co, &p.nt, &p.nblk);
         else conv_choose_tiles(d.co, &p.nt, &p.nblk);
         std::vector<int> &m = maps[i];
@@ -173,7 +174,8 @@ int pack_all(b2f_ctx *c, const float *flat)
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
         p.w_off = total;
         total += p.wino == 4 ? wino4_wpk_floats(chunks, p.nblk) : p.wino == 1 ? narrow2_wpk_floats(chunks)
-                 : p.wino == 3 ? c16_wpk_floats() : p.wino == 2 ? wino_wpk_floats(chunks, p.nt, p.nblk) : conv_wpk_floats(chunks, p.nt, p.nblk);
+                 : p.wino == 3 ? c16_wpk_floats() : p.wino == 5 ? c16s2_wpk_floats() : p.wino == 2 ? wino_wpk_floats(chunks, p.nt, p.nblk)
+                 : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
         if (p.wino == 4) {
@@ -209,6 +211,8 @@ int pack_all(b2f_ctx *c, const float *flat)
                                  host.data() + p.b_off);
         else if (p.wino == 3)
             c16_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), host.data() + p.w_off, host.data() + p.b_off);
+        else if (p.wino == 5)
+            c16s2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), host.data() + p.w_off, host.data() + p.b_off);
         else if (p.wino == 2)
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
                               host.data() + p.w_off, host.data() + p.b_off);
@@ -369,16 +373,17 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? "C16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? "C16" : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
+        snprintf(name, sizeof name, mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
     if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
     else if (mode == 3) HIPCHK(launch_conv3x3_c16(L, s));
+    else if (mode == 5) HIPCHK(launch_conv3x3_c16s2(L, s));
     else if (mode == 2) HIPCHK(launch_conv3x3_wino(L, s));
     else HIPCHK(launch_conv3x3(L, s));
     return 0;
@@ -1277,20 +1282,21 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     const int chunks = (Ci + kCK - 1) / kCK, Cp = chunks * kCK;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     int nt, nblk;
-    int wino = (stride == 1 && use_wino() && Ci == 16 && Co == 16) ? 3 : stride == 1 ? wino_mode(Co) : 0;
+    int wino = (stride == 1 && use_wino() && Ci == 16 && Co == 16) ? 3 : (stride == 2 && use_wino() && Ci == 16 && Co == 32) ? 5 : stride == 1 ? wino_mode(Co) : 0;
     // tests: option op_wino_split = 1 runs F(4x4)-eligible layers on the F(2x2) kernel, one block per 32-output N tile
     const bool op_split = c->op_wino_split && wino == 4 && Co > 32;
     if (op_split) wino = 2;
     if (wino == 4) { nt = 2; nblk = wino4_nblk(Co); }
-    else if (wino == 1 || wino == 3) { nt = 1; nblk = 1; }
+    else if (wino == 1 || wino == 3 || wino == 5) { nt = 1; nblk = 1; }
     else if (wino == 2) wino_choose_tiles(Co, &nt, &nblk);
     else conv_choose_tiles(Co, &nt, &nblk);
     std::vector<float> wpk(wino == 4 ? wino4_wpk_floats(chunks, nblk) : wino == 1 ? narrow2_wpk_floats(chunks)
-                           : wino == 3 ? c16_wpk_floats() : wino == 2 ? wino_wpk_floats(chunks, nt, nblk) : conv_wpk_floats(chunks, nt, nblk)),
+                           : wino == 3 ? c16_wpk_floats() : wino == 5 ? c16s2_wpk_floats() : wino == 2 ? wino_wpk_floats(chunks, nt, nblk) : conv_wpk_floats(chunks, nt, nblk)),
         bpk((size_t)nblk * nt * 32);
     if (wino == 4) wino4_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nblk, wpk.data(), bpk.data());
     else if (wino == 1) narrow2_pack_weights(wt, bias, Ci, nullptr, chunks, wpk.data(), bpk.data());
     else if (wino == 3) c16_pack_weights(wt, bias, Ci, nullptr, wpk.data(), bpk.data());
+    else if (wino == 5) c16s2_pack_weights(wt, bias, Ci, nullptr, wpk.data(), bpk.data());
     else if (wino == 2) wino_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     else conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     DevBuf dpl, dx, dw, db, dy, dyp;
@@ -1314,6 +1320,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));
+    else if (wino == 5) HIPCHK(launch_conv3x3_c16s2(L, c->stream));
     else if (wino == 2) HIPCHK(launch_conv3x3_wino(L, c->stream));
     else HIPCHK(launch_conv3x3(L, c->stream));
     HIPCHK(launch_nhwc_to_planar(dy.p, Co, Co, B, Ho, Wo, dyp.p, c->stream));

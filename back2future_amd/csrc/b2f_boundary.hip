@@ -47,11 +47,8 @@ __global__ void scale_rows_kernel(const float *src, int normalize, long planes, 
     const long dx = (long)(i % Wd);
     const size_t row = i / Wd;                 // plane * Hs + y
     const int ch = (int)((row / Hs) % 3);
-    const float mean[3] = {0.485f, 0.456f, 0.406f};
-    const float stdv[3] = {0.229f, 0.224f, 0.225f};
-    const float m = -mean[ch], sd = stdv[ch];
     const float *s = src + row * Ws;
-    dst[i] = scale_line_elem([&](long k) { const float v = s[k]; return normalize ? __fdiv_rn(v + m, sd) : v; }, Ws, Wd, dx);
+    dst[i] = scale_line_elem([&](long k) { const float v = s[k]; return normalize ? color_normalize(v, ch) : v; }, Ws, Wd, dx);
 }
 
 // columns: [planes][Hs][Wd] -> [planes][Hd][Wd]

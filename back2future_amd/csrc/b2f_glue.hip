@@ -14,15 +14,13 @@ __global__ void pack_input_kernel(const float *in, int normalize, int B, int H, 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * hw) return;
     const size_t b = i / hw, p = i - b * hw;
-    const float mean[3] = {0.485f, 0.456f, 0.406f};
-    const float stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float x = in[(b * 9 + f * 3 + c) * hw + p];
-            if (normalize) x = __fdiv_rn(x + (-mean[c]), stdv[c]);   // add(-mean) then div(std)
+            if (normalize) x = color_normalize(x, c);
             v[c] = x;
         }
         float4 *o = reinterpret_cast<float4 *>(img + (((size_t)f * B + b) * hw + p) * kImgC);
@@ -207,7 +205,7 @@ hipError_t launch_warp_image_planar(const float *img8, const float *flow_planar,
 // 96 B/pixel of HBM writes).  HBM-bound: 36 B read + 48 B written per input pixel.  Block = 256
 // threads = 8 x 32 output pixels of one (frame, batch) image; the 17 x 65 x 3 input patch is
 // normalized once into LDS; weights [tap 27][cout 16] come in as scalar (SGPR) operands.
-__global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int normalize, int B, int H, int W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void conv_first_kernel(const float *in, int normalize, int B, int H, int W,
                                                          const float *wt /*27 x 16*/, const float *bias /*16*/,
                                                          float *out /*[3][B][2][H/2*W/2][8]*/)
 {
@@ -223,8 +221,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int no
     const int f = img / B, b = img - f * B;
     const int ox0 = tx_i * TW, oy0 = ty_i * TH;
     const int ix0 = 2 * ox0 - 1, iy0 = 2 * oy0 - 1;
-    const float mean[3] = {0.485f, 0.456f, 0.406f};
-    const float stdv[3] = {0.229f, 0.224f, 0.225f};
     const size_t hw = (size_t)H * W;
     const float *src = in + ((size_t)b * 9 + (size_t)f * 3) * hw;
     // staging without integer divisions: wave w takes patch rows (c, py) = w, w + 4, ... (51 rows = 13 per wave, the
@@ -245,6 +241,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int no
             const int gx = ix0 + lane, gx64 = ix0 + 64;
             ok[i] = row_ok && gx >= 0 && gx < W;
             ok64[i] = row_ok && lane == 0 && gx64 < W;
+#ifdef B2F_CF_ABLATE
+            if (B2F_CF_ABLATE & 2) { v[i] = (float)gx; v64[i] = (float)gy; continue; }
+#endif
             v[i] = rowp[ok[i] ? gx : 0];
             v64[i] = rowp[ok64[i] ? gx64 : 0];
         }
@@ -254,9 +253,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int no
             const int c = r >= 2 * PH ? 2 : (r >= PH ? 1 : 0), py = r - c * PH;
             if (r < 3 * PH) {
                 float a = v[i], b = v64[i];
-                if (normalize) {                         // add(-mean) then div(std)
-                    a = __fdiv_rn(a + (-mean[c]), stdv[c]);
-                    b = __fdiv_rn(b + (-mean[c]), stdv[c]);
+                if (normalize) {
+                    a = color_normalize(a, c);
+                    b = color_normalize(b, c);
                 }
                 patch[c][py][lane] = ok[i] ? a : 0.f;    // zero padding of the NORMALIZED image
                 if (lane == 0) patch[c][py][64] = ok64[i] ? b : 0.f;
@@ -283,6 +282,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float *in, int no
     if (oy >= Ho || ox >= Wo) return;
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = acc[o] > 0.f ? acc[o] : 0.2f * acc[o];
+#ifdef B2F_CF_ABLATE
+    if ((B2F_CF_ABLATE & 1) && acc[0] != 12345.678f) return;
+#endif
     const size_t hwo = (size_t)Ho * Wo;
     float *op = out + (size_t)img * hwo * 16 + ((size_t)oy * Wo + ox) * 8;
     *reinterpret_cast<float4 *>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -418,15 +420,13 @@ __global__ void warp_input_planar_kernel(const float *in, int normalize, int fra
     bhwd_top_left(v + (float)y, H, yt, wy);
     const int dx = (xl + 1 <= W - 1) ? 1 : 0, dy = (yt + 1 <= H - 1) ? W : 0;   // weight is 0 when folded
     const float w00 = wx * wy, w01 = (1.f - wx) * wy, w10 = wx * (1.f - wy), w11 = (1.f - wx) * (1.f - wy);
-    const float mean[3] = {0.485f, 0.456f, 0.406f};
-    const float stdv[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float *src = in + (b * 9 + (size_t)frame * 3 + c) * hw + (size_t)yt * W + xl;
         float tl = src[0], tr = src[dx], bl = src[dy], br = src[dy + dx];
         if (normalize) {
-            tl = __fdiv_rn(tl + (-mean[c]), stdv[c]); tr = __fdiv_rn(tr + (-mean[c]), stdv[c]);
-            bl = __fdiv_rn(bl + (-mean[c]), stdv[c]); br = __fdiv_rn(br + (-mean[c]), stdv[c]);
+            tl = color_normalize(tl, c); tr = color_normalize(tr, c);
+            bl = color_normalize(bl, c); br = color_normalize(br, c);
         }
         out[(b * 3 + c) * hw + p] = w00 * tl + w01 * tr + w10 * bl + w11 * br;
     }

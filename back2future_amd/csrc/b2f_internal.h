@@ -70,6 +70,11 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
 hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s);
 size_t c16_wpk_floats();
 void c16_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, float *wpk, float *bpk);
+// 16 -> 32 channels, stride 2 (mode 5): the same single-pass scheme
+bool c16s2_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_c16s2(const ConvLaunch &p, hipStream_t s);
+size_t c16s2_wpk_floats();
+void c16s2_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, float *wpk, float *bpk);
 // ---- 2-output stride-1 layers (last decoder layer): VALU kernel in b2f_glue.hip, weights [chunk][tap][8][2]
 hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s);
 size_t narrow2_wpk_floats(int cin_chunks);
@@ -88,6 +93,25 @@ void wino4_pack_weights(const float *w, const float *b, int Co, int Ci, const in
                         int nblk, float *wpk, float *bpk);
 void wino_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map,
                        int cin_chunks, int nt, int nblk, float *wpk, float *bpk);
+
+// ColorNormalize's (x + (-mean_c)) / std_c (transforms.lua:33-45; constants of back2future.lua:33-36) with the IEEE quotient but
+// without the ~11-instruction float division: y = RN(1 / std), a' = a / 16, q = a' y, r = fma(-q, std, a'), q' = fma(r, y, q),
+// result 16 q' (Markstein's correction step on a scaled dividend: q cannot overflow before the quotient does; a itself where a
+// is inf / NaN).  tools/div_const_check.hip compares it with __fdiv_rn on the GPU for EVERY float32 bit pattern of x and the
+// three channels: 0 of 3 x 2^32 results differ.
+__device__ __forceinline__ float color_normalize(float x, int c)
+{
+    constexpr float mean[3] = {0.485f, 0.456f, 0.406f};
+    constexpr float stdv[3] = {0.229f, 0.224f, 0.225f};
+    constexpr float rcp[3] = {(float)(1.0 / (double)0.229f), (float)(1.0 / (double)0.224f), (float)(1.0 / (double)0.225f)};
+    const float a = x + (-mean[c]);              // add(-mean) then div(std)
+    const float as = a * 0.0625f;
+    const float q = as * rcp[c];
+    const float r = __builtin_fmaf(-q, stdv[c], as);
+    float f = __builtin_fmaf(r, rcp[c], q) * 16.f;
+    if (!(__builtin_fabsf(a) < __builtin_inff())) f = a;
+    return f;
+}
 
 // ---- fused warp + cost volume -----------------------------------------------------
 struct CorrLaunch {

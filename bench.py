@@ -66,13 +66,13 @@ def conv_layers(H, W):
     return out
 
 
-MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "D1": "conv3x3_s1", "D2": "conv3x3_s2"}
+MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2"}
 
 
 def layer_kernels(model, step, torch):
     """Kernel class of every conv layer AS THE LIBRARY RAN IT: one eager pass with option profile_layers, whose rows are named
     conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
-    C16 = 16 -> 16 kernel, D1 / D2 = direct kernel stride 1 / 2).  Returns {(cin_padded, cout, H_in, W_in): class}."""
+    C16 = 16 -> 16 kernel, S16 = 16 -> 32 stride-2 kernel, D1 / D2 = direct kernel stride 1 / 2).  Returns {(cin_padded, cout, H_in, W_in): class}."""
     model.set_option("use_graph", 0)
     model.set_option("profile_layers", 1)
     model.set_option("profile", 1)
@@ -86,7 +86,7 @@ def layer_kernels(model, step, torch):
     import re
     out = {}
     for name, (ms, n) in rows.items():
-        m = re.match(r"^conv(W4|W2|N2|C16|D1|D2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
         if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
             out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
     return out

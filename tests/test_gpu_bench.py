@@ -33,8 +33,8 @@ def test_single_gpu_line_contract():
     assert d["value"] > 0 and d["outputs_finite"]
     # the per-layer kernel classes are read back from the library (not re-derived): every conv layer of the pruned graph is there
     layers = d["conv_kernel_of_layer"]["layers"]
-    assert layers["16to16_64x128"] == "conv3x3_c16" and layers["32to2_32x64"] == "conv3x3_narrow2" and layers["16to32_64x128"] == "conv3x3_s2"
-    assert set(layers.values()) <= {"conv3x3_wino4", "conv3x3_wino", "conv3x3_narrow2", "conv3x3_c16", "conv3x3_s1", "conv3x3_s2"}
+    assert layers["16to16_64x128"] == "conv3x3_c16" and layers["32to2_32x64"] == "conv3x3_narrow2" and layers["16to32_64x128"] == "conv3x3_s2x16" and layers["32to64_32x64"] == "conv3x3_s2"
+    assert set(layers.values()) <= {"conv3x3_wino4", "conv3x3_wino", "conv3x3_narrow2", "conv3x3_c16", "conv3x3_s2x16", "conv3x3_s1", "conv3x3_s2"}
     assert "compute_flow_hard_exact" in d and "two_pipelines_in_flight" in d
 
 

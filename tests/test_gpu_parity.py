@@ -47,7 +47,8 @@ def test_weights_roundtrip(hard):
     (128, 192, 2, 8, 14, True), (192, 192, 1, 4, 7, True), (196, 128, 1, 16, 33, True), (32, 2, 1, 20, 17, False),
     (5, 7, 1, 3, 5, False), (64, 32, 1, 1, 2, True), (64, 64, 1, 40, 70, True), (8, 68, 1, 18, 34, False),
     (128, 128, 1, 33, 65, True), (16, 16, 1, 5, 37, False), (16, 16, 1, 35, 66, True), (32, 2, 1, 33, 18, True),
-    (40, 32, 1, 17, 33, True), (24, 96, 1, 20, 40, True), (16, 32, 2, 24, 40, True), (16, 32, 2, 9, 33, False)])
+    (40, 32, 1, 17, 33, True), (24, 96, 1, 20, 40, True), (16, 32, 2, 24, 40, True), (16, 32, 2, 9, 33, False),
+    (16, 32, 2, 7, 131, True), (16, 32, 2, 1, 1, True), (16, 32, 2, 18, 64, False), (12, 32, 2, 10, 12, True)])
 def test_conv3x3(hard, ci, co, stride, h, w, leaky):
     r = _rng(ci * 1000 + co)
     x = r.standard_normal((2, ci, h, w), dtype=np.float32)
@@ -344,6 +345,28 @@ def test_image_scale_bit_exact(hard, Hs, Ws, Hd, Wd, normalize):
     exp = O.image_scale_bilinear(O.color_normalize(src) if normalize else src, Hd, Wd)
     got = ops.image_scale(hard, src, Hd, Wd, normalize)
     np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_color_normalize_is_the_ieee_quotient(hard):
+    """The device ColorNormalize forms (x - mean) / std without a float division (scaled Markstein correction step,
+    b2f_internal.h:color_normalize; tools/div_const_check.hip proves it for every float32 on the GPU): same bits as numpy's
+    division on pixel values, on every float32 neighbour of the means, on huge, tiny, infinite and NaN inputs."""
+    r = _rng(77)
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    near = np.concatenate([np.nextafter(np.full(40, m, np.float32), np.float32(d)) for m in mean for d in (0, 1)])
+    for k in range(1, 40):
+        near[k::40] = np.nextafter(near[k - 1::40], np.float32(1) if k % 2 else np.float32(0))
+    special = np.array([0, -0.0, 1, 1e-45, -1e-45, 1e-38, 3e38, -3e38, 7.7e37, -7.7e37, 7.8e37, 3.4028235e38, np.inf, -np.inf, np.nan,
+                        255, 1 / 255, 0.5, 2 ** -126, 1e20, -1e20], np.float32)
+    wide = (r.standard_normal(4000) * np.exp(r.uniform(-80, 88, 4000))).astype(np.float32)
+    vals = np.concatenate([r.random(9 * 64 * 64 - near.size - special.size - wide.size).astype(np.float32), near, special, wide])
+    src = r.permutation(vals).reshape(9, 64, 64)
+    with np.errstate(all="ignore"):
+        exp = O.color_normalize(src)
+    got = ops.image_scale(hard, src, 64, 64, True)           # identity scale: the normalization alone
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    np.testing.assert_array_equal(got.view(np.uint32)[ok], exp.view(np.uint32)[ok])
 
 
 @pytest.mark.parametrize("which,H0,W0", [("soft", 150, 200), ("hard", 131, 259)])
