@@ -5,7 +5,7 @@
 // shape gets its own single-pass direct kernel on v_mfma_f32_16x16x4_f32 (exact fp32, same 256 FLOP/clk/CU):
 //   D[co 16][pixel 16] += A[co][k 4] * B[k][pixel],  K = 9 taps x 16 channels = 36 MFMAs per 16 pixels.
 // Block = 256 threads -> 16 x 32 output pixels; the 18 x 34 x 16-channel patch is staged once into LDS as
-// [channel quad kg 4][pixel] float4 (39 KB, four blocks per CU); lane (n = l & 15, kg = l >> 4) reads the
+// [channel quad kg 4][pixel] float4 (39 KB; round 3: double-buffered, two persistent blocks per CU); lane (n = l & 15, kg = l >> 4) reads the
 // float4 of pixel n / quad kg per tap (conflict-free) and feeds 4 MFMAs (k = 4 kg + j); the weights of
 // the lane's (co = l & 15, kg) stay in 36 VGPRs for the whole kernel.  A lane ends up with 4 consecutive output
 // channels of one pixel: bias, LeakyReLU, one 16-byte store.  Chunk-planar in and out.
@@ -17,27 +17,36 @@ namespace b2f {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA of one piece: lane i's 16 bytes at (resource base + voff) land at LDS byte address lds + 16 i; an offset past the
+// resource's size reads as zero.  Invisible to the compiler's s_waitcnt bookkeeping: the kernels wait themselves.
+__device__ __forceinline__ void c16_dma(int voff, i32x4 rsrc, unsigned lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)lds)) : "memory");
+}
+
 namespace c16 {
 constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2;
 constexpr int NPIX = PH * PW;          // 612
 constexpr int PLANE = 628;             // float4 per channel-quad plane (>= NPIX; 628 * 16 B = 64 B mod 256: the four planes start 16 banks apart)
+constexpr int NPC = (NPIX + 63) / 64;  // 1-KB DMA pieces per plane: 10 (the last one 36 lanes wide)
+constexpr int BUF_F4 = 4 * PLANE;
+constexpr int LDS_BYTES = 2 * BUF_F4 * 16;   // 80 384: two blocks per CU
 }  // namespace c16
 
-__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvLaunch p)
+// Round 3: persistent (two blocks per CU walk the tiles), the patch of the NEXT tile brought into the other half of a
+// double-buffered LDS patch by LDS-DMA (wave w = channel quad w, one 1-KB piece per tap under the MFMAs of the first M tiles;
+// out-of-image pixels read as zero through the buffer resource's range check) -- see conv3x3_c16s2_kernel below, same scheme.
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvLaunch p, const int ntiles, const int tiles_x, const int tiles_y)
 {
     using namespace c16;
-    __shared__ f32x4 patch[4][PLANE];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const f32x4 *L = reinterpret_cast<const f32x4 *>(smem);                 // [2][4][PLANE]
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
-
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx_i = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty_i = bid % tiles_y;
-    const int img = bid / tiles_y;
-    const int ox0 = tx_i * TW, oy0 = ty_i * TH;
 
     // weights of (co = n, channel quad kg): 9 taps x float4 (ci = 4 kg + j)
     f32x4 wv[9];
@@ -46,56 +55,91 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvLaunch p)
     for (int t = 0; t < 9; ++t) wv[t] = wp[t * 64];
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + 4 * kg);
 
-    // ---- stage the patch: item = (pixel, kg); channel quad kg lives in chunk kg >> 1, half kg & 1 ----
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
-    // 2448 items = 9.6 per thread: all loads (from clamped addresses, no branch) are issued before the first LDS
-    // write, so the block pays one memory round trip instead of ten
-    {
-        constexpr int NIT = (4 * NPIX + 255) / 256;
-        f32x4 v[NIT];
-        bool ok[NIT];
+    // DMA items of this wave: channel quad `wave` (chunk wave >> 1, half wave & 1), patch pixel 64 j + lane
+    int pyx[NPC];
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = tid + k * 256;
-            const int pix = i >> 2, q = i & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-            ok[k] = i < 4 * NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const unsigned gp = ok[k] ? (unsigned)(gy * p.W + gx) : 0u;
-            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsrc, (int)((gp * (unsigned)p.seg[0].pix_stride + (q & 1) * 4 + (unsigned)(q >> 1) * (unsigned)p.seg[0].chunk_stride) * 4u), 0, 0));
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = tid + k * 256;
-            if (i < 4 * NPIX) patch[i & 3][i >> 2] = ok[k] ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int j = 0; j < NPC; ++j) {
+        const int slot = 64 * j + lane;
+        const int py = slot / PW, px = slot - py * PW;
+        pyx[j] = slot < NPIX ? (py << 8 | px) : -1;
     }
-    __syncthreads();
+    const int qoff = ((wave & 1) * 4 + (wave >> 1) * (int)p.seg[0].chunk_stride) * 4;
+    const int img_bytes = (int)(p.seg[0].img_stride * 4);
 
-    float *ob = p.out + (size_t)img * p.out_img_stride + (size_t)(kg >> 1) * p.out_chunk_stride + (kg & 1) * 4;
-    // 32 tiles of 16 pixels (16 rows x 2 column halves), 8 per wave
-#pragma unroll 2
-    for (int q = 0; q < 8; ++q) {
-        const int mt = wave * 8 + q;
-        const int ry = mt >> 1, xt = mt & 1;
-        const f32x4 *pp = &patch[kg][ry * PW + xt * 16 + n];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    struct Tile { int img, ox0, oy0; };
+    auto decode = [&](int v) {
+        int bid = xcd_remap(v, ntiles);
+        Tile t;
+        const int tx_i = bid % tiles_x;
+        bid /= tiles_x;
+        const int ty_i = bid % tiles_y;
+        t.img = bid / tiles_y;
+        t.ox0 = tx_i * TW; t.oy0 = ty_i * TH;
+        return t;
+    };
+    auto resource = [&](const Tile &t) {
+        const unsigned long long base = reinterpret_cast<unsigned long long>(p.seg[0].ptr + (size_t)t.img * p.seg[0].img_stride);
+        const i32x4 rsrc = {(int)(unsigned)base, (int)((unsigned)(base >> 32) & 0xffffu), img_bytes, 0x00020000};
+        return rsrc;
+    };
+    auto issue_piece = [&](const Tile &t, const i32x4 rsrc, int buf, int j) {
+        if (pyx[j] >= 0) {
+            const int gy = t.oy0 - 1 + (pyx[j] >> 8), gx = t.ox0 - 1 + (pyx[j] & 255);
+            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int off = ok ? (gy * p.W + gx) * (int)p.seg[0].pix_stride * 4 + qoff : 0x7ffffff0;   // past the image: zero
+            c16_dma(off, rsrc, lds0 + (unsigned)((buf * BUF_F4 + wave * PLANE + 64 * j) * 16));
+        }
+    };
+
+    const int G = gridDim.x;
+    int v = blockIdx.x;
+    Tile cur = decode(v < ntiles ? v : 0);
+    if (v < ntiles) {
+        const i32x4 r0 = resource(cur);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < NPC; ++j) issue_piece(cur, r0, 0, j);
+    }
+    static_assert(NPC <= 18, "the pieces are issued under the taps of the first two M tiles");
+    bool prev_full = false;            // the previous tile issued all eight stores of a lane (seven of them behind this tile's last piece)
+    int buf = 0;
+    for (; v < ntiles; v += G, buf ^= 1) {
+        // this wave's pieces of the current tile have landed (vmcnt counts in order: the last piece was issued in front of the
+        // stores of M tiles 1..7 of the previous tile, which may stay in flight when there are exactly seven of them)
+        if (prev_full) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();               // everyone's pieces landed; everyone is done reading the other buffer
+        const int vn = v + G;
+        const bool more = vn < ntiles;
+        const Tile nxt = more ? decode(vn) : cur;
+        const i32x4 rn = resource(nxt);
+        const f32x4 *patch = L + buf * BUF_F4 + kg * PLANE;
+        float *ob = p.out + (size_t)cur.img * p.out_img_stride + (size_t)(kg >> 1) * p.out_chunk_stride + (kg & 1) * 4;
+        // 32 tiles of 16 pixels (16 rows x 2 column halves), 8 per wave
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 a = pp[ky * PW + kx];
-                const f32x4 w = wv[ky * 3 + kx];
+        for (int q = 0; q < 8; ++q) {
+            const int mt = wave * 8 + q;
+            const int ry = mt >> 1, xt = mt & 1;
+            const f32x4 *pp = patch + ry * PW + xt * 16 + n;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], a[j], acc, 0, 0, 0);
-            }
-        // lane (n, kg) holds D[co = 4 kg + r][pixel n], r = 0..3
-        f32x4 v = acc + bias;
-        if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);
-        const int oy = oy0 + ry, ox = ox0 + xt * 16 + n;
-        if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4 *>(ob + ((size_t)oy * p.W + ox) * p.out_pix_stride) = v;
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int step = q * 9 + ky * 3 + kx;
+                    if (more && step < NPC) issue_piece(nxt, rn, buf ^ 1, step);     // one piece per tap, the first NPC taps
+                    const f32x4 a = pp[ky * PW + kx];
+                    const f32x4 w = wv[ky * 3 + kx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], a[j], acc, 0, 0, 0);
+                }
+            // lane (n, kg) holds D[co = 4 kg + r][pixel n], r = 0..3
+            f32x4 o4 = acc + bias;
+            if (p.leaky) o4 = __builtin_elementwise_max(o4, 0.2f * o4);
+            const int oy = cur.oy0 + ry, ox = cur.ox0 + xt * 16 + n;
+            if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4 *>(ob + ((size_t)oy * p.W + ox) * p.out_pix_stride) = o4;
+        }
+        prev_full = cur.oy0 + TH <= p.H && cur.ox0 + TW <= p.W;
+        cur = nxt;
     }
 }
 
@@ -104,15 +148,39 @@ bool c16_supported(const ConvLaunch &p)
     return p.stride == 1 && p.cout == 16 && p.nseg == 1 && p.seg[0].nchunks == 2 && p.H == p.Ho && p.W == p.Wo &&
            (p.seg[0].pix_stride & 3) == 0 && (p.seg[0].chunk_stride & 3) == 0 && (p.out_pix_stride & 3) == 0 &&
            (p.out_chunk_stride & 3) == 0 &&
-           ((double)p.H * p.W * p.seg[0].pix_stride + (double)p.seg[0].chunk_stride) * 4.0 < 2147483648.0;   // 32-bit buffer offsets
+           (double)p.seg[0].img_stride * 4.0 < 2147483632.0;   // 32-bit buffer offsets; the image is the buffer resource
+}
+
+// persistent launch shared by the two kernels of this file: BPC blocks per CU (fewer when the launch has fewer tiles)
+template <typename K>
+static hipError_t launch_persistent(K kernel, const ConvLaunch &p, int tiles_x, int tiles_y, int lds_bytes, int bpc, bool &attr_done, int &n_cu, hipStream_t s)
+{
+    const int ntiles = tiles_x * tiles_y * p.nimg;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (!n_cu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n &= ~7;                                  // the XCD banding of the logical tile index wants a multiple of 8
+        n_cu = n < 8 ? 8 : n;
+    }
+    int grid = bpc * n_cu < ntiles ? bpc * n_cu : ntiles;
+    if (grid >= 8) grid &= ~7;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds_bytes, s, p, ntiles, tiles_x, tiles_y);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s)
 {
     if (!c16_supported(p)) return hipErrorInvalidValue;
-    const int tiles = ((p.W + c16::TW - 1) / c16::TW) * ((p.H + c16::TH - 1) / c16::TH);
-    hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p);
-    return hipGetLastError();
+    static bool attr_done_dev[64] = {false};
+    static int n_cu_dev[64] = {0};
+    const int slot = attr_slot();
+    return launch_persistent(conv3x3_c16_kernel, p, (p.W + c16::TW - 1) / c16::TW, (p.H + c16::TH - 1) / c16::TH, c16::LDS_BYTES, 2,
+                             attr_done_dev[slot], n_cu_dev[slot], s);
 }
 
 size_t c16_wpk_floats() { return 9 * 4 * 16 * 4; }
@@ -158,15 +226,6 @@ static_assert(NPC <= 9 * NXT, "one piece per tap");
 constexpr int BUF_F4 = 4 * PLANE;
 constexpr int LDS_BYTES = 2 * BUF_F4 * 16;   // 75 264 | 42 496
 }  // namespace c16s2
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// LDS-DMA of one piece: lane i's 16 bytes at (resource base + voff) land at LDS byte address lds + 16 i; an offset past the
-// resource's size reads as zero.  Invisible to the compiler's s_waitcnt bookkeeping: the kernel waits itself.
-__device__ __forceinline__ void c16s2_dma(int voff, i32x4 rsrc, unsigned lds)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)lds)) : "memory");
-}
 
 __global__ __launch_bounds__(256) void conv3x3_c16s2_kernel(const ConvLaunch p, const int ntiles, const int tiles_x, const int tiles_y)
 {
@@ -221,7 +280,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16s2_kernel(const ConvLaunch p, 
             const int gy = 2 * t.oy0 - 1 + (pyx[j] >> 8), gx = 2 * t.ox0 - 1 + (pyx[j] & 255);
             const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const int off = ok ? (gy * p.W + gx) * (int)p.seg[0].pix_stride * 4 + qoff : 0x7ffffff0;   // past the image: zero
-            c16s2_dma(off, rsrc, lds0 + (unsigned)((buf * BUF_F4 + wave * PLANE + 64 * j) * 16));
+            c16_dma(off, rsrc, lds0 + (unsigned)((buf * BUF_F4 + wave * PLANE + 64 * j) * 16));
         }
     };
 
@@ -299,26 +358,11 @@ bool c16s2_supported(const ConvLaunch &p)
 hipError_t launch_conv3x3_c16s2(const ConvLaunch &p, hipStream_t s)
 {
     if (!c16s2_supported(p)) return hipErrorInvalidValue;
-    const int tiles_x = (p.Wo + c16s2::TW - 1) / c16s2::TW, tiles_y = (p.Ho + c16s2::TH - 1) / c16s2::TH;
-    const int ntiles = tiles_x * tiles_y * p.nimg;
     static bool attr_done_dev[64] = {false};
     static int n_cu_dev[64] = {0};
     const int slot = attr_slot();
-    if (!attr_done_dev[slot]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_c16s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c16s2::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done_dev[slot] = true;
-    }
-    if (!n_cu_dev[slot]) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        n &= ~7;                                  // the XCD banding of the logical tile index wants a multiple of 8
-        n_cu_dev[slot] = n < 8 ? 8 : n;
-    }
-    int grid = c16s2::BLOCKS_PER_CU * n_cu_dev[slot] < ntiles ? c16s2::BLOCKS_PER_CU * n_cu_dev[slot] : ntiles;
-    if (grid >= 8) grid &= ~7;
-    hipLaunchKernelGGL(conv3x3_c16s2_kernel, dim3((unsigned)grid), dim3(256), c16s2::LDS_BYTES, s, p, ntiles, tiles_x, tiles_y);
-    return hipGetLastError();
+    return launch_persistent(conv3x3_c16s2_kernel, p, (p.Wo + c16s2::TW - 1) / c16s2::TW, (p.Ho + c16s2::TH - 1) / c16s2::TH, c16s2::LDS_BYTES,
+                             c16s2::BLOCKS_PER_CU, attr_done_dev[slot], n_cu_dev[slot], s);
 }
 
 size_t c16s2_wpk_floats() { return 9 * 2 * 4 * 16 * 4; }
