@@ -331,6 +331,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     if (p.wino == 4) {
         if (!c->adaptive_kernels) {
             alt = H * W < c->wino4_min_pixels;
+            split = alt && p.nt2 == 2 && H * W <= c->wino_split_pixels;
         } else {
             // cost in twentieths of a lone F(2x2) block: F(4x4) block 60; F(2x2) block 20 alone, 40 per pair sharing a CU;
             // F(2x2) block that computes one of the two N tiles only 13 / 26
@@ -755,6 +756,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
             return end == v ? 1ll : x;
         };
         c->wino4_min_pixels = (int)env_int("B2F_WINO4_MIN_PIXELS", c->wino4_min_pixels);
+        c->wino_split_pixels = (int)env_int("B2F_WINO_SPLIT_PIXELS", c->wino_split_pixels);
         c->adaptive_kernels = (int)env_int("B2F_ADAPTIVE_KERNELS", c->adaptive_kernels);
         c->corr_variant = (int)env_int("B2F_CORR_VARIANT", env_int("B2F_CORR_LAT", c->corr_variant));   // B2F_CORR_LAT: the round-1 name
         c->op_wino_split = (int)env_int("B2F_OP_WINO_SPLIT", c->op_wino_split);
@@ -888,6 +890,12 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         drop_graphs(c);
         (key[0] == 's' ? c->s2_tiles_per_block : c->wino4_persistent) = value;
     }
+    else if (!strcmp(key, "wino_split_pixels")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        c->wino_split_pixels = value;
+    }
     else if (!strcmp(key, "wino4_min_pixels") || !strcmp(key, "adaptive_kernels")) {
         // a different kernel mix: captured graphs hold the old one
         HIPCHK(hipSetDevice(c->device));
@@ -928,6 +936,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
+    else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
     else if (k == "corr_variant") *value = c->corr_variant;
     else if (k == "corr_ablate") *value = c->corr_ablate;

@@ -182,7 +182,9 @@ B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh
  * (eager mode); profile_layers = one profile row per layer shape.
  * Kernel selection: wino4_min_pixels (default 4096) = stride-1 convs run the Winograd F(4x4)
  * kernel on maps of at least that many pixels and F(2x2) below -- a rule of the map size only,
- * so a triplet's result never depends on the batch it is computed in; adaptive_kernels = 1
+ * so a triplet's result never depends on the batch it is computed in; wino_split_pixels (default
+ * 512) = F(2x2) launches on maps of at most that many pixels run one block per 32 outputs
+ * (twice the blocks for the coarsest level; same bits); adaptive_kernels = 1
  * picks the variant per launch by block rounds on the 256 CUs instead (faster for single
  * triplets, results then vary at the 1e-6 level with the batch size); corr_variant (-1 auto /
  * 0 .. 6) forces an instantiation of the warp + cost-volume kernel (same bits either way);
