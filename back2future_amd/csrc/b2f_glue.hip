@@ -98,67 +98,88 @@ __device__ __forceinline__ float2 bilerp2(const float *in, int ps, int h, int w,
     return o;
 }
 
-__global__ void upsample_flow2x_kernel(const float *in, int ps, int B, int h, int w, float *out, int planar)
+// One thread = four consecutive output pixels of a row (grid: x groups, output row, image -- no integer divisions); 16-byte
+// stores where the row length allows them.
+__global__ __launch_bounds__(256) void upsample_flow2x_kernel(const float *in, int ps, int B, int h, int w, float *out, int planar)
 {
     const int H2 = 2 * h, W2 = 2 * w;
-    const size_t n = (size_t)B * H2 * W2;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x2 = (int)(i % W2);
-    const size_t r = i / W2;
-    const int y2 = (int)(r % H2);
-    const int b = (int)(r / H2);
+    const int x0 = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int y2 = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (x0 >= W2) return;
     const float rh = (H2 > 1) ? (float)(h - 1) / (float)(H2 - 1) : 0.f;
     const float rw = (W2 > 1) ? (float)(w - 1) / (float)(W2 - 1) : 0.f;
-    const float2 o = bilerp2(in + (size_t)b * h * w * ps, ps, h, w, rh, rw, y2, x2);
+    const float *src = in + (size_t)b * h * w * ps;
+    float2 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = bilerp2(src, ps, h, w, rh, rw, y2, min(x0 + k, W2 - 1));
+    const size_t hw2 = (size_t)H2 * W2, row = (size_t)y2 * W2 + x0;
     if (planar) {
-        const size_t hw2 = (size_t)H2 * W2;
-        out[((size_t)b * 2) * hw2 + (size_t)y2 * W2 + x2] = o.x;
-        out[((size_t)b * 2 + 1) * hw2 + (size_t)y2 * W2 + x2] = o.y;
+        float *o0 = out + ((size_t)b * 2) * hw2 + row, *o1 = o0 + hw2;
+        if ((W2 & 3) == 0) {
+            *reinterpret_cast<float4 *>(o0) = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+            *reinterpret_cast<float4 *>(o1) = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x0 + k < W2) { o0[k] = o[k].x; o1[k] = o[k].y; }
+        }
     } else {
-        reinterpret_cast<float2 *>(out)[i] = o;
+        float2 *op = reinterpret_cast<float2 *>(out) + (size_t)b * hw2 + row;
+        if ((W2 & 3) == 0) {
+            *reinterpret_cast<float4 *>(op) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+            *reinterpret_cast<float4 *>(op + 2) = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x0 + k < W2) op[k] = o[k];
+        }
     }
 }
 
-hipError_t launch_upsample_flow2x(const float *in, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
+static hipError_t launch_upsample(const float *in, int in_pix_stride, int B, int h, int w, float *out, int planar, hipStream_t s)
 {
-    const size_t n = (size_t)B * 4 * h * w;
-    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_pix_stride, B, h, w, out, 0);
+    if (B <= 0 || h <= 0 || w <= 0) return hipSuccess;
+    if (2 * h > 65535 || B > 65535) return hipErrorInvalidValue;
+    const int groups = (2 * w + 3) / 4;
+    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((groups + 255) / 256), (unsigned)(2 * h), (unsigned)B), dim3(256), 0, s, in,
+                       in_pix_stride, B, h, w, out, planar);
     return hipGetLastError();
 }
-
+hipError_t launch_upsample_flow2x(const float *in, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
+{
+    return launch_upsample(in, in_pix_stride, B, h, w, out, 0, s);
+}
 hipError_t launch_upsample_flow2x_planar(const float *in, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
 {
-    const size_t n = (size_t)B * 4 * h * w;
-    hipLaunchKernelGGL(upsample_flow2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, in_pix_stride, B, h, w, out, 1);
-    return hipGetLastError();
+    return launch_upsample(in, in_pix_stride, B, h, w, out, 1, s);
 }
 
 // ---- nn.SpatialSoftMax over the 2 decoder logits (pwc.lua:308) + two
-// nn.SpatialUpSamplingNearest(2) (pwc.lua:311-321) -> planar B x 2 x 4h x 4w. ----
-__global__ void softmax_nearest4_kernel(const float *logits, int ps, int B, int h, int w, float *out)
+// nn.SpatialUpSamplingNearest(2) (pwc.lua:311-321) -> planar B x 2 x 4h x 4w.  One thread = one source pixel's four output
+// columns of one output row (the softmax once, two 16-byte stores). ----
+__global__ __launch_bounds__(256) void softmax_nearest4_kernel(const float *logits, int ps, int B, int h, int w, float *out)
 {
     const int H4 = 4 * h, W4 = 4 * w;
-    const size_t n = (size_t)B * H4 * W4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int X = (int)(i % W4);
-    const size_t r = i / W4;
-    const int Y = (int)(r % H4);
-    const int b = (int)(r / H4);
-    const float2 z = *reinterpret_cast<const float2 *>(logits + (((size_t)b * h + Y / 4) * w + X / 4) * ps);
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);       // source column
+    const int Y = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (x >= w) return;
+    const float2 z = *reinterpret_cast<const float2 *>(logits + (((size_t)b * h + (Y >> 2)) * w + x) * ps);
     const float m = fmaxf(z.x, z.y);
     const float e0 = expf(z.x - m), e1 = expf(z.y - m);
     const float sum = e0 + e1;
+    const float p0 = e0 / sum, p1 = e1 / sum;
     const size_t hw4 = (size_t)H4 * W4;
-    out[((size_t)b * 2) * hw4 + (size_t)Y * W4 + X] = e0 / sum;
-    out[((size_t)b * 2 + 1) * hw4 + (size_t)Y * W4 + X] = e1 / sum;
+    float *o0 = out + ((size_t)b * 2) * hw4 + (size_t)Y * W4 + 4 * x;
+    *reinterpret_cast<float4 *>(o0) = make_float4(p0, p0, p0, p0);
+    *reinterpret_cast<float4 *>(o0 + hw4) = make_float4(p1, p1, p1, p1);
 }
 
 hipError_t launch_softmax_nearest4_planar(const float *logits, int in_pix_stride, int B, int h, int w, float *out, hipStream_t s)
 {
-    const size_t n = (size_t)B * 16 * h * w;
-    hipLaunchKernelGGL(softmax_nearest4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, in_pix_stride, B, h, w, out);
+    if (B <= 0 || h <= 0 || w <= 0) return hipSuccess;
+    if (4 * h > 65535 || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_nearest4_kernel, dim3((unsigned)((w + 255) / 256), (unsigned)(4 * h), (unsigned)B), dim3(256), 0, s, logits,
+                       in_pix_stride, B, h, w, out);
     return hipGetLastError();
 }
 
