@@ -334,7 +334,11 @@ __global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long
                                                            float *out, long out_img_stride, int out_pix_stride, int leaky)
 {
     constexpr int T = 16, P = T + 2, NP = P * P;     // 324 patch pixels
-    __shared__ float4 patch[4][2][NP + 4];
+#ifndef B2F_N2_CPB
+#define B2F_N2_CPB 2
+#endif
+    constexpr int CPB = B2F_N2_CPB;                  // input chunks staged per pass: 2 -> 21 KB of LDS, seven blocks per CU (4: 42 KB, three)
+    __shared__ float4 patch[CPB][2][NP + 4];
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
     int bid = blockIdx.x;
     const int tx_i = bid % tiles_x;
@@ -345,11 +349,11 @@ __global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     const float *src = in + (size_t)img * img_stride;
     float a0 = bias[0], a1 = bias[1];
-    for (int c0 = 0; c0 < nchunks; c0 += 4) {
-        const int nc = min(4, nchunks - c0);
+    for (int c0 = 0; c0 < nchunks; c0 += CPB) {
+        const int nc = min(CPB, nchunks - c0);
         if (c0) __syncthreads();
         // all loads (clamped addresses, no branch) in flight before the first LDS write
-        constexpr int NIT = (4 * 2 * NP + 255) / 256;
+        constexpr int NIT = (CPB * 2 * NP + 255) / 256;
         float4 v[NIT];
         bool ok[NIT];
 #pragma unroll
