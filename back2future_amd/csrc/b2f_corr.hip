@@ -852,16 +852,20 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     //      0.72 / 0.30 / 0.108 ms at levels 3 / 4 / 5 against 0.69 / 0.29 / 0.113 of variant 3 -- the DMA round trip does
     //      hide under the FMAs (ablating it saves 0.03 ms), but the half-chunk phases double the barriers and the
     //      per-phase LDS latency chains (profiles/r02_corr_experiments.txt (10))
-    //   5  the persistent "unit" form of b2f_corr5.hip (C a multiple of 32; other C run variant 3)
+    //   5  the persistent "unit" form of b2f_corr5.hip (C a multiple of 16; other C run variant 3)
+    //   6  its role-specialised form (FMA waves / gather waves with the LDS-DMA window), opt-in
+    //   7  ten unit waves + six gather waves per 1 024-thread block: the default for maps of up to 2 048 pixels (levels 6, 7 of a
+    //      full-HD triplet: 0.043 / 0.031 ms against 0.050 / 0.038 of variant 5)
     const bool win_ok = p.w <= 4096 && p.h <= 4096;
     // default: by the map size for the small maps (so that a triplet's kernel does not depend on the batch it is computed in; the
-    // instantiations are bit-identical anyway): the unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet: 0.053 / 0.039
-    // ms against 0.060 / 0.081 at batch 16), else by the launch size
+    // instantiations are bit-identical anyway): the sixteen-wave unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet:
+    // 0.043 / 0.031 ms against 0.060 / 0.081 of the block-per-tile kernels at batch 16), else by the launch size
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
-                  : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 5 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
-    if ((variant == 5 || variant == 6) && !warp_costvol_unit_supported(p)) variant = 3;
+                  : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 7 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+    if ((variant == 5 || variant == 6 || variant == 7) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
     if (variant == 6) return launch_warp_costvol_spec(p, s);
+    if (variant == 7) return launch_warp_costvol_gw(p, s);
     if (variant == 4) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_win_kernel<true>), dim3(2 * g2.x), dim3(128), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_win_kernel<false>), dim3(2 * g2.x), dim3(128), 0, s, p);

@@ -987,6 +987,164 @@ __global__ __launch_bounds__(512) void warp_costvol_spec_kernel(const CorrLaunch
     }
 #undef C6_BLEND
 #undef C6_BB
+}
+
+// ---- sixteen waves (corr_variant 7): ten unit waves + six gather waves ----------------------------------------------------
+// The two lessons of variants 5 and 6 put together: the FMAs want the ten 8-channel unit waves of variant 5 (a SIMD needs three
+// issuing waves to retire an FMA every 1.67 cycles; one wave issues one every 5.5), and everything that waits for memory wants
+// to sit in waves that do nothing else.  Block = 1 024 threads: waves 0..9 compute one unit per stage from LDS (and store a
+// finished tile-direction), waves 10..15 gather the taps of the NEXT stage's warped halo straight from memory (two items = 16
+// loads per thread in flight, no window), blend them into the other halo buffer, DMA the reference tile and compute the sampling
+// records a stage ahead.  128 registers per thread; one LDS-only barrier per stage.
+namespace v7 {
+constexpr int NF = 10, NG = 6;
+constexpr int NTHR = 64 * (NF + NG);            // 1 024
+constexpr int GT = 64 * NG;                     // 384 gather threads
+constexpr int NIT = 2 * v5::NHP / GT;           // blend items per gather thread and stage: 2
+constexpr int NRJ = v5::NHP / GT;               // sampling records per gather thread and tile-direction: 1
+static_assert(2 * v5::NHP % GT == 0 && v5::NHP % GT == 0 && GT % 2 == 0, "items divide over the gather threads");
+constexpr int OFF_HALO = 0, OFF_REF = OFF_HALO + 2 * v5::HALO_F4, OFF_REC = OFF_REF + 2 * v5::REF_F4;
+constexpr int LDS_BYTES = 16 * (OFF_REC + v5::NREC * v5::NHP);   // 84 480
+}  // namespace v7
+
+template <bool POW2>
+__global__ __launch_bounds__(1024) void warp_costvol_gw_kernel(const CorrLaunch p, const int ntd, const int tiles_x, const int tiles_y)
+{
+    using namespace v5;
+    using v7::NF;
+    using v7::NG;
+    using v7::GT;
+    using v7::NIT;
+    using v7::NRJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *L = reinterpret_cast<float4 *>(smem);
+    float4 *halo = L + v7::OFF_HALO;
+    float4 *refb = L + v7::OFF_REF;
+    float4 *recs = L + v7::OFF_REC;
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int ncg = p.C / CGC;
+    const int nmine = (ntd - (int)blockIdx.x + G - 1) / G;
+    const int S = nmine * ncg;
+    const bool gth = wave >= NF;
+    const int gw = wave - NF, gt = tid - NF * 64;
+    const int ghp = gt >> 1, ghh = gt & 1;                        // blend items of a gather thread: halo pixels ghp + (GT / 2) i, half ghh
+    const int pr = lane >> 4, lx = lane & 15;
+
+    const int step = G >> 3;
+    int q_lin, q_tx, q_ty, q_b, q_k = 0;
+    C5Tile t0, t1, t2, t3, t4;
+    {
+        q_lin = xcd_remap((int)blockIdx.x, ntd);
+        const int tile = q_lin >> 1;
+        q_tx = tile % tiles_x;
+        q_ty = (tile / tiles_x) % tiles_y;
+        q_b = tile / (tiles_x * tiles_y);
+    }
+    C5_NEWEST(t0); C5_ADVANCE(); C5_NEWEST(t1); C5_ADVANCE(); C5_NEWEST(t2); C5_ADVANCE(); C5_NEWEST(t3); C5_ADVANCE(); C5_NEWEST(t4);
+#define C7_TAPS(tt_, cgn_, k1_)                                                                                      \
+    _Pragma("unroll") for (int i__ = 0; i__ < NIT; ++i__)                                                            \
+        if (B2F_C5_ABLATE & 1) { _Pragma("unroll") for (int q__ = 0; q__ < 4 * NCC; ++q__) tp[i__][q__] = make_float4(1.f, 2.f, 3.f, 4.f); sm[i__].w4 = make_float4(.25f, .25f, .25f, .25f); } else \
+        c5_taps(p, tt_, cgn_, recs + ((k1_) % NREC) * NHP, false, 0, 0, nullptr, ghp + (GT / 2) * i__, ghh, tp[i__], sm[i__])
+#define C7_BLEND(hbuf_)                                                                                              \
+    _Pragma("unroll") for (int i__ = 0; i__ < NIT; ++i__)                                                            \
+        c5_blend(halo + (hbuf_) * HALO_F4, ghp + (GT / 2) * i__, ghh, tp[i__], sm[i__])
+
+    // ---- prologue (gather waves): records of the first tile-directions, reference tile and warped halo of stage 0
+    float2 fa = make_float2(0.f, 0.f), fb = fa, fc = fa;
+    if (gth) {
+        for (int q = 0; q < nmine && q * ncg <= 2; ++q) {
+            C5Tile tt;
+            C5_PICK(tt, q);
+            c5_rec_issue<NRJ, GT>(p, tt, gt, fa, fb, fc);
+            c5_rec_finish<NRJ, GT, false>(p, tt, gt, fa, fb, fc, recs + (q % NREC) * NHP, nullptr);
+        }
+        if (3 % ncg == 0 && 3 / ncg < nmine) {
+            C5Tile tt;
+            C5_PICK(tt, 3 / ncg);
+            c5_rec_issue<NRJ, GT>(p, tt, gt, fa, fb, fc);
+        }
+        c5_ref_dma<NG>(p, t0, 0, lds0 + 16u * v7::OFF_REF, gw, lane);
+    }
+    __syncthreads();
+    if (gth) {
+        float4 tp[NIT][4 * NCC];
+        C5Samp sm[NIT];
+        C7_TAPS(t0, 0, 0);
+        C7_BLEND(0);
+        C5_VM_DRAIN();
+    }
+    __syncthreads();
+
+    if (gth) {
+        int s = 0;
+        for (int k = 0; k < nmine; ++k) {
+            for (int cg = 0; cg < ncg; ++cg, ++s) {
+                const bool last_cg = cg + 1 == ncg;
+                // flows of the tile-direction that stage s + 4 opens (consumed a stage later), reference tile of stage s + 1
+                float2 na = fa, nb = fb, nc = fc;
+                {
+                    int dk, cgo;
+                    C5_AHEAD(4, cg, dk, cgo);
+                    if (cgo == 0 && k + dk < nmine) {
+                        C5Tile tt;
+                        C5_PICK(tt, dk);
+                        c5_rec_issue<NRJ, GT>(p, tt, gt, na, nb, nc);
+                    }
+                }
+                float4 tp[NIT][4 * NCC];
+                C5Samp sm[NIT];
+                if (s + 1 < S) {
+                    C5Tile tt;
+                    C5_PICK(tt, last_cg ? 1 : 0);
+                    c5_ref_dma<NG>(p, tt, last_cg ? 0 : cg + 1, lds0 + 16u * (v7::OFF_REF + ((s + 1) & 1) * REF_F4), gw, lane);
+                    const int k1 = last_cg ? k + 1 : k;
+                    C7_TAPS(tt, last_cg ? 0 : cg + 1, k1);            // 16 loads per thread in flight under the record pass
+                }
+                {   // sampling records of the tile-direction that stage s + 3 opens (flows issued a stage ago)
+                    int dk, cgo;
+                    C5_AHEAD(3, cg, dk, cgo);
+                    if (cgo == 0 && k + dk < nmine && (k + dk) * ncg > 2) {
+                        C5Tile tt;
+                        C5_PICK(tt, dk);
+                        c5_rec_finish<NRJ, GT, false>(p, tt, gt, fa, fb, fc, recs + ((k + dk) % NREC) * NHP, nullptr);
+                    }
+                    fa = na; fb = nb; fc = nc;
+                }
+                if (s + 1 < S) C7_BLEND((s + 1) & 1);
+                C5_VM_DRAIN();
+                C5_LDS_BARRIER();
+            }
+            t0 = t1; t1 = t2; t2 = t3; t3 = t4;
+            C5_ADVANCE();
+            C5_NEWEST(t4);
+        }
+    } else {
+        float acc[18];
+#pragma unroll
+        for (int e = 0; e < 18; ++e) acc[e] = 0.f;
+        int s = 0;
+        for (int k = 0; k < nmine; ++k) {
+            for (int cg = 0; cg < ncg; ++cg, ++s) {
+                const float4 *hb = halo + (s & 1) * HALO_F4 + (2 * pr + R) * HW + (lx + R);
+                const float4 *rb = refb + (s & 1) * REF_F4 + (2 * pr) * TW + lx;
+                if (!(B2F_C5_ABLATE & 2)) {
+                    if (t0.dir == 0) c5_units<0>(wave, hb, rb, acc);
+                    else c5_units<1>(wave, hb, rb, acc);
+                }
+                if (cg + 1 == ncg) corr5_store<POW2>(p, t0, t0.dir, wave, pr, lx, acc);
+                C5_LDS_BARRIER();
+            }
+            t0 = t1; t1 = t2; t2 = t3; t3 = t4;
+            C5_ADVANCE();
+            C5_NEWEST(t4);
+        }
+    }
+#undef C7_BLEND
+#undef C7_TAPS
 #undef C5_VM_DRAIN
 #undef C5_LDS_BARRIER
 #undef C5_AHEAD
@@ -1047,6 +1205,35 @@ hipError_t launch_warp_costvol_spec(const CorrLaunch &p, hipStream_t s)
         }
     }
 #endif
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_costvol_gw(const CorrLaunch &p, hipStream_t s)
+{
+    using namespace v5;
+    if (!warp_costvol_unit_supported(p)) return hipErrorInvalidValue;
+    static bool attr_done_dev[64][2] = {{false}};
+    static int n_cu_dev[64] = {0};
+    const int slot = attr_slot();
+    const bool pow2 = (p.C & (p.C - 1)) == 0;
+    if (!attr_done_dev[slot][pow2 ? 1 : 0]) {
+        const void *fn = pow2 ? reinterpret_cast<const void *>(&warp_costvol_gw_kernel<true>) : reinterpret_cast<const void *>(&warp_costvol_gw_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, v7::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done_dev[slot][pow2 ? 1 : 0] = true;
+    }
+    if (!n_cu_dev[slot]) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n &= ~7;
+        n_cu_dev[slot] = n < 8 ? 8 : n;
+    }
+    const int tiles_x = (p.w + TW - 1) / TW, tiles_y = (p.h + TH - 1) / TH;
+    const int ntd = 2 * tiles_x * tiles_y * p.B;
+    int grid = n_cu_dev[slot] < ntd ? n_cu_dev[slot] : ntd;
+    if (grid >= 8) grid &= ~7;
+    if (pow2) hipLaunchKernelGGL((warp_costvol_gw_kernel<true>), dim3((unsigned)grid), dim3(v7::NTHR), v7::LDS_BYTES, s, p, ntd, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((warp_costvol_gw_kernel<false>), dim3((unsigned)grid), dim3(v7::NTHR), v7::LDS_BYTES, s, p, ntd, tiles_x, tiles_y);
     return hipGetLastError();
 }
 

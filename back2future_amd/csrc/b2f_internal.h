@@ -166,6 +166,8 @@ bool warp_costvol_unit_supported(const CorrLaunch &p);
 hipError_t launch_warp_costvol_unit(const CorrLaunch &p, hipStream_t s);
 // the role-specialised form of it (variant 6): FMA waves and gather waves, source window by LDS-DMA
 hipError_t launch_warp_costvol_spec(const CorrLaunch &p, hipStream_t s);
+// ten unit waves + six gather waves per block (variant 7)
+hipError_t launch_warp_costvol_gw(const CorrLaunch &p, hipStream_t s);
 // generic (any odd win) single-direction cost volume, NHWC in, B x h x w x win*win out
 hipError_t launch_costvol_generic(const float *ref, const float *frm, int B, int C, int h, int w,
                                   int win, int fwd, float *out, hipStream_t s);

@@ -187,7 +187,7 @@ B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh
  * (twice the blocks for the coarsest level; same bits); adaptive_kernels = 1
  * picks the variant per launch by block rounds on the 256 CUs instead (faster for single
  * triplets, results then vary at the 1e-6 level with the batch size); corr_variant (-1 auto /
- * 0 .. 6) forces an instantiation of the warp + cost-volume kernel (same bits either way);
+ * 0 .. 7) forces an instantiation of the warp + cost-volume kernel (same bits either way);
  * wino4_persistent (default 1) = F(4x4) launches run as persistent blocks, one per CU
  * (0: one tile per block; same bits either way); s2_tiles_per_block
  * (default 0 = launcher's rule) = tiles a block of the stride-2 kernel chains (same bits).
