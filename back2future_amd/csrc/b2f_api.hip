@@ -243,7 +243,7 @@ struct Plan {
     bool full;          // full model:forward table (all decoders, image pyramid, image warps)
     int rec;            // cost-volume record size in floats
     int h[8], w[8];
-    size_t img, tmp, cs[8], U[8], UB[8], cv, d[6], d2[6], fs, bfs, logits, u2, flow_planar, ds[6], total;
+    size_t img, tmp, cs[8], U[8], UB[8], cv, d[6], fs, bfs, logits, u2, flow_planar, ds[6], total;
 };
 
 Plan make_plan(int B, int H, int W, bool full, bool past_flow)
@@ -263,8 +263,6 @@ Plan make_plan(int B, int H, int W, bool full, bool past_flow)
     p.cv = take((size_t)B * p.h[3] * p.w[3] * p.rec + 64);
     const size_t px3 = (size_t)B * p.h[3] * p.w[3];
     for (int i = 1; i <= 5; ++i) p.d[i] = take(px3 * kDec[i]);
-    // second set of decoder intermediates: the level-3 occlusion decoder of the pruned graph runs beside the flow decoder
-    for (int i = 1; i <= 5; ++i) p.d2[i] = full ? 0 : take(px3 * kDec[i]);
     p.fs = take(px3 * 8);       // conv outputs are chunk-planar: 2 channels live in one 8-float chunk
     p.bfs = take(px3 * 8);
     p.logits = take(px3 * 8);
@@ -391,9 +389,9 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
 }
 
 // decoder(n) of pwc.lua:76-85 at level l; input = {cs[ref][l], cost-volume record}
-int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, int l, float *out2, const size_t *dbuf = nullptr)
+int run_decoder(b2f_ctx *c, hipStream_t s, bool cap, const Plan &P, int kind, int l, float *out2)
 {
-    if (!dbuf) dbuf = P.d;
+    const size_t *dbuf = P.d;
     float *A = c->arena;
     const int h = P.h[l], w = P.w[l], B = P.B;
     const size_t hw = (size_t)h * w;
@@ -430,7 +428,6 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
     const int B = P.B;
     const bool full = P.full, past = c->past_flow && full;
     const int unit = in_kind == B2F_IN_UNIT;
-    bool forked = false;
     if (full) {   // the packed frames are only needed for the image pyramid / image warps of the full table
         Scope sc(c, s, "pack_input", cap);
         HIPCHK(launch_pack_input((const float *)dev_in, unit, B, P.H, P.W, A + P.img, s));
@@ -495,23 +492,14 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         float *occ_out = full ? O.t_occ[l] : (l == 3 ? O.occ : nullptr);
         float *occ_out2 = (!full && l == 3 && c->past_flow) ? O.est3 : nullptr;   // Soft: est[3] = skip_occs[3]
         if (occ_out || occ_out2) {
-            // pruned graph, level 3: the occlusion decoder depends on the cost volume only, so it runs on the side stream beside
-            // the flow decoder + up-sampling + image warp (own intermediates P.d2; joined at the end of the pass).  Both chains are
-            // chip-filling kernels: what overlaps is each chain's launch gaps, tails and small kernels with the other's big ones.
-            const bool par = !full && c->parallel_decoders && c->s_side && P.d2[1];
-            hipStream_t so = par ? c->s_side : s;
-            if (par) {
-                HIPCHK(hipEventRecord(c->ev_fork, s));
-                HIPCHK(hipStreamWaitEvent(so, c->ev_fork, 0));
-                forked = true;
-            }
-            CHK(run_decoder(c, so, cap, P, KIND_OCC, l, A + P.logits, par ? P.d2 : P.d));
+            // (round 3 ran this decoder on a side stream beside the flow decoder: both chains are chip-filling persistent
+            // kernels, measured no gain, and the second set of intermediates cost a third of the arena -- removed in round 4)
+            CHK(run_decoder(c, s, cap, P, KIND_OCC, l, A + P.logits));
             {
-                Scope sc(c, so, "softmax_nearest4", cap);
-                if (occ_out) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out, so));
-                if (occ_out2) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out2, so));
+                Scope sc(c, s, "softmax_nearest4", cap);
+                if (occ_out) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out, s));
+                if (occ_out2) HIPCHK(launch_softmax_nearest4_planar(A + P.logits, 8, B, h, w, occ_out2, s));
             }
-            if (par) HIPCHK(hipEventRecord(c->ev_join, so));
         }
         CHK(run_decoder(c, s, cap, P, KIND_FLOW, l, A + P.fs));
         if (past) CHK(run_decoder(c, s, cap, P, KIND_PAST, l, A + P.bfs));
@@ -549,7 +537,6 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         HIPCHK(launch_warp_input_planar((const float *)dev_in, unit, 0, O.flow ? O.flow : A + P.flow_planar, -20.0f, B, P.H, P.W,
                                         O.est3, s));
     }
-    if (forked) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));   // join: the side stream's work is part of this pass
     return 0;
 }
 
@@ -619,19 +606,6 @@ int install_weights(b2f_ctx *c, const float *flat, long long n, bool past)
 }
 
 }  // namespace
-
-// The side stream of option parallel_decoders exists only while that option is on: an extra stream per context shares the
-// device's few hardware queues with the three streams of the host pipeline (measured: b2f_compute_flow_batch 545 -> 410 triplets/s
-// with an idle fourth stream created at init).
-static int ensure_side_stream(b2f_ctx *c)
-{
-    if (c->s_side) return 0;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamCreateWithFlags(&c->s_side, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    return 0;
-}
 
 // ======================================================================================
 extern "C" {
@@ -771,17 +745,12 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
         c->host_u8 = (int)env_int("B2F_HOST_U8", c->host_u8);
         c->host_ramp = (int)env_int("B2F_HOST_RAMP", c->host_ramp);
-        c->parallel_decoders = (int)env_int("B2F_PARALLEL_DECODERS", c->parallel_decoders);
     }
     // a blocking stream: ordered with the legacy default stream like any such stream, so inputs that PyTorch (whose
     // default stream is the null stream) or hipMemcpy / hipMemset produced there are complete before our kernels read them
     if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
         delete c;
         return fail("b2f_init: hipStreamCreate failed");
-    }
-    if (c->parallel_decoders && ensure_side_stream(c) != 0) {
-        b2f_destroy(c);
-        return 1;
     }
     if (install_weights(c, flat.data(), (long long)flat.size(), past) != 0) {
         b2f_destroy(c);
@@ -797,7 +766,6 @@ void b2f_destroy(b2f_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->s_side) (void)hipStreamSynchronize(c->s_side);
     drop_graphs(c);
     drop_gen_out(c);
     for (ProfEvent &pe : c->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
@@ -813,9 +781,6 @@ void b2f_destroy(b2f_ctx *c)
     if (c->arena) (void)hipFree(c->arena);
     if (c->wpk_dev) (void)hipFree(c->wpk_dev);
     if (c->w_dev) (void)hipFree(c->w_dev);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->s_side) (void)hipStreamDestroy(c->s_side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -913,13 +878,6 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_u8")) c->host_u8 = value;
     else if (!strcmp(key, "host_ramp")) c->host_ramp = value;
     else if (!strcmp(key, "debug_fail_next")) c->debug_fail_next = value;
-    else if (!strcmp(key, "parallel_decoders")) {
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipDeviceSynchronize());
-        drop_graphs(c);
-        if (value) CHK(ensure_side_stream(c));
-        c->parallel_decoders = value;
-    }
     else return fail(std::string("b2f_set_option: unknown key ") + key);
     return 0;
 }
@@ -946,7 +904,6 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "host_u8") *value = c->host_u8;
     else if (k == "host_ramp") *value = c->host_ramp;
     else if (k == "debug_fail_next") *value = c->debug_fail_next;
-    else if (k == "parallel_decoders") *value = c->parallel_decoders;
     else return fail("b2f_get_option: unknown key " + k);
     return 0;
 }
@@ -999,7 +956,7 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
     HIPCHK(hipSetDevice(c->device));
     if (!c->g.shipped()) {
         // other graph shapes: the whole output table through the generic executor (b2f_graph.hip), then est[1] / the
-        // finest occlusion map / est[3] into the caller's buffers.  Synchronous, no hipGraph: a correctness path.
+        // finest occlusion map / est[3] into the caller's buffers.  Asynchronous on the stream like the tuned path, no hipGraph: a correctness path.
         const int n = c->g.n_outputs(), per = c->past_flow ? 5 : 4, lst = c->g.l_st();
         // the output table lives in the context and is re-allocated only when the shape changes (a hipMalloc / hipFree pair per
         // call is device-synchronising and stalled the upload / download overlap of the host pipeline: ADVICE r2)
@@ -1065,6 +1022,9 @@ int b2f_forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int H
                        float *dev_occ, float *dev_est3, void *stream) try
 {
     if (!c || !dev_in) return fail("b2f_forward_device: null argument");
+    // the glue kernels read / write these planes with 16-byte vector accesses (include/b2f.h states the requirement)
+    if (((uintptr_t)dev_in | (uintptr_t)dev_flow | (uintptr_t)dev_occ | (uintptr_t)dev_est3) & 15)
+        return fail("b2f_forward_device: device buffers must be 16-byte aligned");
     return forward_device(c, dev_in, in_kind, B, H, W, dev_flow, dev_occ, dev_est3, stream ? (hipStream_t)stream : c->stream,
                           c->use_graph != 0);
 }

@@ -201,10 +201,6 @@ struct b2f_ctx {
     b2f::GraphOpts g;           // graph shape (createModelMulti options); g.past_flow == past_flow
     long long nparams = 0;
     hipStream_t stream = nullptr;
-    // side stream of the forward pass: the level-3 occlusion decoder runs on it beside the flow decoder (fork / join with two
-    // events; inside a captured hipGraph the two chains become parallel branches)
-    hipStream_t s_side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<b2f::ConvDesc> lay;
     std::vector<b2f::PackedConv> packed;
     float *w_dev = nullptr;     // flat canonical weights
@@ -235,8 +231,6 @@ struct b2f_ctx {
     long long host_subbatch_pixels = 16ll << 20;
     int host_threads = 0;          // 0 = auto
     int host_u8 = 1, host_ramp = 1;
-    int parallel_decoders = 0;     // 1: level-3 occlusion decoder on the side stream, beside the flow decoder (same bits; measured: no
-                                   // gain, 746.9 vs 748.7 triplets/s -- both chains are chip-filling persistent kernels that simply alternate)
     int debug_fail_next = 0;       // tests: the next b2f_compute_flow* call on this context fails (cross-thread error hand-over of b2f_multi_*)
     std::map<b2f::GraphKey, hipGraphExec_t> graphs;
     // output table of the generic executor (non-shipped graph shapes), kept between calls of one (B, H, W)

@@ -11,6 +11,7 @@
 //     buffers.  No data-path collective: computeFlow keeps no cross-sample state.
 #include "b2f_ctx.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -98,6 +99,11 @@ int broadcast_weights(b2f_multi *m, int *transport)
             if (c) (void)r.CommDestroy(c);
         if (rc == ncclSuccess && he == hipSuccess) done = true;
         else why = rc != ncclSuccess ? std::string("RCCL: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?") : std::string("HIP: ") + hipGetErrorString(he);
+        // a HIP error here (stream sync / set device) is a faulted device, not a transport problem: no peer copies on top of it
+        if (he != hipSuccess) return api_fail("b2f_init_multi: weight broadcast failed (" + why + ")");
+        if (!done) fprintf(stderr, "libb2f: RCCL weight broadcast failed (%s); falling back to hipMemcpyPeer\n", why.c_str());
+    } else if (*transport == 1) {
+        fprintf(stderr, "libb2f: librccl.so not loadable; weight broadcast by hipMemcpyPeer\n");
     }
     if (!done) {
         *transport = 2;

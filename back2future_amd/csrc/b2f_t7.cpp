@@ -328,8 +328,11 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
         if (mod && class_is(mod, "nn.CostVolMulti")) {
             Ref wn = field(mod, "win");
             if (wn && wn->num > 0) {
-                if (file_win && file_win != (int)wn->num) { err = "CostVolMulti nodes with different windows"; return false; }
-                file_win = (int)wn->num;
+                // untrusted input: range-check the double before it becomes an int (GraphOpts::valid(): odd, 1..15)
+                const double wv = wn->num;
+                if (!(wv >= 1.0 && wv <= 15.0) || wv != (double)(int)wv || !((int)wv & 1)) { err = "CostVolMulti window outside 1..15 / not an odd integer"; return false; }
+                if (file_win && file_win != (int)wv) { err = "CostVolMulti nodes with different windows"; return false; }
+                file_win = (int)wv;
             }
         }
         if (!mod || !class_is(mod, "nn.Sequential") || seen_seq.count(mod.get())) continue;
@@ -367,6 +370,8 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
         g = GraphOpts();
         if (file_win) g.win = file_win;
         g.levels = feat.rbegin()->first;
+        // win / levels in range before they enter occ_in() / flow_in() (win * win) below; skip is inferred later
+        if (!(g.win >= 1 && (g.win & 1) && g.win <= 15 && g.levels >= 2 && g.levels <= 7)) { err = "the file's graph shape is outside what this library runs: " + graph_opts_string(g); return false; }
     } else if (file_win && file_win != g.win) {
         err = "the file's cost volumes use a " + std::to_string(file_win) + "-wide window, the graph options say " + std::to_string(g.win);
         return false;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frame-triplets/sec of the computeFlow hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU.  A step = one pass of the whole computeFlow device pipeline
@@ -220,6 +220,32 @@ def host_path(torch, model, H, W, n=32):
             "single_triplet_ms_bytes_in": 1e3 * t_1, "finite": bool(np.isfinite(out[0]).all())}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this same command line, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1 at a free port).  The parent
+    has not initialised the GPU (nothing is exec'd over a process that has); rank 0's stdout is relayed verbatim."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+    return max(abs(c) for c in rcs) and 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,6 +269,11 @@ def main():
     if args.no_extras:
         args.no_cpu_baseline = args.no_host_path = True
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process never touches the GPU (torch is not even imported yet); it
+        # starts the N ranks as children, relays rank 0's single JSON line and exits with the worst child's code
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from back2future_amd import back2future
@@ -251,8 +282,6 @@ def main():
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the computeFlow path has no CPU fallback")
@@ -309,8 +338,12 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every_t, t)
+        per_rank = [B * args.steps / float(u.item()) for u in every_t]     # a straggler shows here
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -401,6 +434,8 @@ def main():
         }
         if bcast:
             out["weights_broadcast"] = bcast
+        if per_rank:
+            out["per_rank_value"] = {"unit": "triplets/s of each rank over its own wall time (value uses the slowest rank's)", "values": per_rank}
         if hard_dt is not None:
             out["compute_flow_hard_exact"] = {
                 "what": "same workload without the level-3 occlusion decoder: everything computeFlow() of an Ours-Hard model reads "

@@ -165,6 +165,8 @@ B2F_API int b2f_multi_compute_flow_batch_u8(b2f_multi *m, int n, const unsigned 
  *   dev_occ   B x 2 x H x W   skip_occs[3] (softmax probabilities)
  *   dev_est3  B x C3 x H x W  est[3] as computeFlow reads it: C3 = 2 (Soft: the
  *                             occlusion map) or 3 (Hard: warped image 1)
+ * Every device pointer must be 16-byte aligned (vector loads / stores; hipMalloc and torch
+ * allocations are, a view at an odd storage offset is not): a misaligned one is rejected.
  * The call is asynchronous on `stream`; the context's own stream (NULL) is a blocking stream
  * (ordered with the legacy default stream, not with other non-blocking streams); results are
  * awaited with b2f_synchronize.                                            */

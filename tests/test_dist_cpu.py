@@ -57,3 +57,19 @@ def test_broadcast_and_shard_two_ranks():
     assert [r[0] for r in res] == [0, 1]
     assert all(r[1] and r[2] for r in res)
     assert sum(r[3] for r in res) == 5
+
+
+def test_bench_plain_invocation_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never imports torch or touches a GPU) starts both
+    ranks and hands back their exit code.  Without a GPU every rank refuses loudly (no CPU fallback), so here rc = 1 and
+    both refusals are visible; the GPU twin is tests/test_gpu_bench.py::test_plain_invocation_spawns_ranks."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"],
+                       capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 1
+    assert r.stderr.count("bench.py needs a GPU") == 2 and "ranks failed" in r.stderr

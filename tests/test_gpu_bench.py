@@ -57,3 +57,16 @@ def test_two_ranks_share_the_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
     assert d["weights_broadcast"]["ranks"] == 2 and d["weights_broadcast"]["checksums_match"] is True
     assert d["value"] > 0 and d["outputs_finite"]
+
+
+def test_plain_invocation_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver's N=1 command line looks with another N):
+    the parent starts the ranks itself, relays rank 0's one line and returns their exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"] + SMALL,
+                       capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
+    assert d["weights_broadcast"]["ranks"] == d["n_gpus"] and d["weights_broadcast"]["checksums_match"] is True
+    assert len(d["per_rank_value"]["values"]) == 2 and all(v > 0 for v in d["per_rank_value"]["values"])

@@ -499,33 +499,6 @@ def test_graph_replay_matches_eager(soft):
         np.testing.assert_array_equal(o, outs[0][1])
 
 
-@pytest.mark.parametrize("which", ["hard", "soft"])
-def test_parallel_decoders_same_bits(hard, soft, which):
-    """Option parallel_decoders (default 0: measured no gain): the level-3 occlusion decoder on the context's side stream, beside the flow decoder
-    (fork / join with events; parallel branches inside a captured hipGraph) -- eager and replayed, against the single-stream order."""
-    import torch
-    m = hard if which == "hard" else soft
-    r = _rng(31)
-    B, H, Wd = 3, 128, 192
-    x = torch.from_numpy(r.standard_normal((B, 9, H, Wd)).astype(np.float32)).cuda()
-    outs = []
-    for par, use_graph in ((0, 0), (1, 0), (1, 1), (1, 1), (1, 1), (0, 1), (0, 1)):
-        m.set_option("parallel_decoders", par)
-        m.set_option("use_graph", use_graph)
-        flow = torch.zeros(B, 2, H, Wd, device="cuda"); occ = torch.zeros(B, 2, H, Wd, device="cuda")
-        est3 = torch.zeros(B, 3 if which == "hard" else 2, H, Wd, device="cuda")
-        torch.cuda.synchronize()
-        m.forward_device(x.data_ptr(), B, H, Wd, flow.data_ptr(), occ.data_ptr(), est3.data_ptr())
-        m.synchronize()
-        outs.append((flow.cpu().numpy(), occ.cpu().numpy(), est3.cpu().numpy()))
-    m.set_option("use_graph", 0)
-    m.set_option("parallel_decoders", 0)
-    assert np.abs(outs[0][1]).max() > 0
-    for o in outs[1:]:
-        for a, b in zip(o, outs[0]):
-            np.testing.assert_array_equal(a, b)
-
-
 def test_host_entry_point_refuses_device_memory(hard):
     import ctypes as C
     import torch
