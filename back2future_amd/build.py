@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libb2f.so")
 BUILD = os.path.join(HERE, "build")
-SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_conv16.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
+SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_wino4s.hip", "b2f_conv16.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
 HEADERS = ["b2f_internal.h", "b2f_host.h", "b2f_ctx.h", "b2f_corr5_loop.inc", os.path.join("..", "..", "include", "b2f.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -55,6 +55,7 @@ struct ConvLaunch {
     int nsplit;         // F(2x2) kernel: 1 = one block per 32-output N tile of the 64-wide packing (more, lighter blocks for small launches)
     int w4_persist = 1;        // F(4x4) kernel: persistent blocks (one per CU) when the launch has at least two tiles per CU
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
+    const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
 // floats needed for the packed weights of a conv with `cin_chunks` K-chunks
@@ -87,6 +88,12 @@ size_t wino_wpk_floats(int cin_chunks, int nt, int nblk);
 // ---- Winograd F(4x4,3x3) variant for the wide stride-1 layers (b2f_wino4.hip): 64 output channels per
 // n-block, weights packed by wino4_pack_weights ([nblk][chunk][xi 36][k4 2][64][4])
 hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s);
+// the same layers on the bf16 matrix pipe with exactly split fp32 operands (b2f_wino4s.hip): n-blocks [nb0, nb0 + nblk) of
+// 64 outputs each, persistent blocks; weights packed by wino4s_pack_weights
+bool wino4s_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_wino4s(const ConvLaunch &p, int nb0, int nblk, hipStream_t s);
+size_t wino4s_wpk_floats(int cin_chunks, int nblk);
+void wino4s_pack_weights(const float *w, int Co, int Ci, const int *cin_map, int cin_chunks, int nblk, float *wpk);
 int wino4_nblk(int cout);
 size_t wino4_wpk_floats(int cin_chunks, int nblk);
 void wino4_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks,

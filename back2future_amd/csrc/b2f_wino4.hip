@@ -1309,7 +1309,10 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
     const int nfull = p.cout / 64, rem = p.cout % 64;
     const int n2 = nfull + (rem > 32 ? 1 : 0);
     hipError_t e = hipSuccess;
-    if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
+    // n-blocks with two full N tiles: on the bf16 matrix pipe with split operands when the layer carries that packing
+    // (b2f_wino4s.hip; persistent form only, K loop of at least 4 chunks), else on the fp32 MFMA
+    if (n2 > 0 && p.w4_persist && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
+    else if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
     if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino4_t<1>(p, nfull, 1, s);
     return e;
 }
