@@ -20,7 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 # b2f_corr: the SLP vectorizer packs the 81 independent FMA chains into v_pk_fma_f32 pairs whose
 # operands are not register-adjacent, which costs ~2 v_mov per FMA; plain v_fmac is faster here.
-EXTRA = {"b2f_corr.hip": ["-fno-slp-vectorize"], "b2f_corr5.hip": ["-fno-slp-vectorize"]}
+# b2f_wino4s: packed fp32 ops do not overlap the bf16 MFMAs (tools/mfma_bf16_chain.hip); its VALU work is written scalar on purpose.
+EXTRA = {"b2f_corr.hip": ["-fno-slp-vectorize"], "b2f_corr5.hip": ["-fno-slp-vectorize"], "b2f_wino4s.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):

@@ -184,9 +184,11 @@ int pack_all(b2f_ctx *c, const float *flat)
             total += wino_wpk_floats(chunks, p.nt2, p.nblk2);
             p.b_off2 = total;
             total += (size_t)p.nblk2 * p.nt2 * 32;
-            total = (total + 3) & ~(size_t)3;        // 16-byte aligned: the split weights are read with dwordx4 loads
-            p.w_off3 = total;
-            total += wino4s_wpk_floats(chunks, p.nblk);
+            if (c->wino4_split) {                    // only while the option is on: 1.5x the F(4x4) packing
+                total = (total + 3) & ~(size_t)3;    // 16-byte aligned: the split weights are read with dwordx4 loads
+                p.w_off3 = total;
+                total += wino4s_wpk_floats(chunks, p.nblk);
+            }
         }
     }
     c->first_w_off = total; total += 27 * 16;
@@ -209,7 +211,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                                host.data() + p.w_off, host.data() + p.b_off);
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt2, p.nblk2,
                               host.data() + p.w_off2, host.data() + p.b_off2);
-            wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
+            if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
         } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
                                  host.data() + p.b_off);
@@ -859,7 +861,9 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
+        const bool repack = (value != 0) != (c->wino4_split != 0);
         c->wino4_split = value;
+        if (repack) CHK(b2f_commit_weights(c));   // the split packing exists only while the option is on
     }
     else if (!strcmp(key, "s2_tiles_per_block") || !strcmp(key, "wino4_persistent")) {
         HIPCHK(hipSetDevice(c->device));

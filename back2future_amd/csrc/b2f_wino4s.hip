@@ -25,10 +25,11 @@
 // packed [n-block][chunk]{ [xi 36][k4 2][co 64] x (Um Um Uh Uh) | [xi][k4][co] x (Ul Ul) }: 24 bytes per lane and xi, one
 // dwordx4 + one dwordx2 buffer load.
 //
-// Block = 256 threads = ONE wave per SIMD with the 512-register budget: wave w owns xi = 9w .. 9w+8 for BOTH N tiles (18
-// accumulators = 288 registers), so each V element is read and split exactly once, nothing is shared between the waves of a
-// SIMD, and MFMAs and the VALU / LDS / memory instructions of the SAME wave interleave (the bf16 pipe takes an MFMA every 32
-// cycles; what a wave issues in between is free).  One barrier per 8-channel chunk, as in the fp32 kernel.
+// Block = 512 threads = two waves per SIMD, wave w = g + 4 n owns xi = 9g .. 9g+8 of N tile n exactly as in conv3x3_wino4p<2>
+// (9 accumulators): while one wave of a SIMD waits for memory or LDS the other one multiplies.  (The first form of this kernel
+// ran ONE wave per SIMD with both N tiles and the 512-register budget: every V element split once, but every s_waitcnt idled
+// the SIMD and 18 accumulators do not fit the 256-register accumulator file -- profiles/r04_wino4s_notes.txt (1).)
+// One barrier per 8-channel chunk, B operands two xi steps ahead (three-slot ring), fp32 A values one step ahead.
 #include "b2f_internal.h"
 
 #include <cmath>
@@ -57,39 +58,43 @@ constexpr int LDS_BYTES = 16 * (2 * RAW_F4 + XQ_F4 + V_F4);   // [raw 0 | raw 1 
 constexpr int U4_BYTES = 36 * 2 * 64 * 16;  // (Um Um Uh Uh) plane of one (n-block, chunk)
 constexpr int U2_BYTES = 36 * 2 * 64 * 8;   // (Ul Ul) plane
 constexpr int UC_BYTES = U4_BYTES + U2_BYTES;
-constexpr int NSTG = 2 * 3 * PW;            // 204 staging threads: (patch row mod 3, patch column, k4), six rows each
+constexpr int NSTG = 2 * 6 * PW;            // 408 staging threads: (patch row mod 6, patch column, k4), three rows each
 __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2); }
 }  // namespace wino4s
 
 #define W4S_FMA(a_, b_, c_) __builtin_elementwise_fma((a_), (b_), (c_))
+#define W4S_F(a_, b_, c_) __builtin_fmaf((a_), (b_), (c_))
 
-// fp32 quad -> window [m01 m23 | h01 h23 | l01 l23] of bf16 pairs (round to nearest even; x = h + m + l exactly)
+// fp32 quad -> window [m01 m23 | h01 h23 | l01 l23] of bf16 pairs (round to nearest even; x = h + m + l exactly).
+// Scalar fp32 subtractions on purpose: a packed fp32 op next to bf16 MFMAs costs ~7 cycles of SIMD time and does not overlap
+// them (tools/mfma_bf16_chain.hip); this file is compiled with -fno-slp-vectorize so that the compiler does not re-pack them.
+__device__ __forceinline__ unsigned w4s_pk(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void w4s_split(const f32x4 v, unsigned (&w)[6])
 {
-    const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
-    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2));
-    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2));
-    const f32x2 hf01 = {__builtin_bit_cast(float, h01 << 16), __builtin_bit_cast(float, h01 & 0xffff0000u)};
-    const f32x2 hf23 = {__builtin_bit_cast(float, h23 << 16), __builtin_bit_cast(float, h23 & 0xffff0000u)};
-    const f32x2 r01 = v01 - hf01, r23 = v23 - hf23;
-    const unsigned m01 = __builtin_bit_cast(unsigned, __builtin_convertvector(r01, bf16x2));
-    const unsigned m23 = __builtin_bit_cast(unsigned, __builtin_convertvector(r23, bf16x2));
-    const f32x2 mf01 = {__builtin_bit_cast(float, m01 << 16), __builtin_bit_cast(float, m01 & 0xffff0000u)};
-    const f32x2 mf23 = {__builtin_bit_cast(float, m23 << 16), __builtin_bit_cast(float, m23 & 0xffff0000u)};
-    const f32x2 l01 = r01 - mf01, l23 = r23 - mf23;
+    const unsigned h01 = w4s_pk(v[0], v[1]), h23 = w4s_pk(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16), r1 = v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16), r3 = v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
+    const unsigned m01 = w4s_pk(r0, r1), m23 = w4s_pk(r2, r3);
+    const float l0 = r0 - __builtin_bit_cast(float, m01 << 16), l1 = r1 - __builtin_bit_cast(float, m01 & 0xffff0000u);
+    const float l2 = r2 - __builtin_bit_cast(float, m23 << 16), l3 = r3 - __builtin_bit_cast(float, m23 & 0xffff0000u);
     w[0] = m01; w[1] = m23; w[2] = h01; w[3] = h23;
-    w[4] = __builtin_bit_cast(unsigned, __builtin_convertvector(l01, bf16x2));
-    w[5] = __builtin_bit_cast(unsigned, __builtin_convertvector(l23, bf16x2));
+    w[4] = w4s_pk(l0, l1);
+    w[5] = w4s_pk(l2, l3);
 }
 
-#ifndef B2F_W4S_ASM8
-#define B2F_W4S_ASM8 1       // 0: the ninth accumulator through the builtin like the others (the compiler then swaps accumulators)
+#ifndef W4S_ACC_REG
+#define W4S_ACC_REG(x_) "v"(x_)      // register class the accumulators live in ("a" if the compiler keeps them in the accumulator file)
 #endif
 #ifndef B2F_W4S_ABLATE
 #define B2F_W4S_ABLATE 0     // profiling only (wrong results): 1 no input transform, 2 no raw staging, 4 no B loads, 8 no MFMAs, 16 no split
 #endif
 
-__global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
+__global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
 {
     using namespace wino4s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31, half = lane >> 5;
+    const int g = wave & 3, n = wave >> 2;
 
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const int total = tiles_x * tiles_y * p.nimg * p.nblk;
@@ -108,23 +113,16 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
     if ((int)blockIdx.x >= total) return;
 
-    // ---- staging of the raw patch: thread tid < 204 = (patch row r3 < 3, patch column px < 34, k4 = tid & 1) stages the six
-    // pixels (r3 + 3 i, px), i = 0..5: one LDS slot and one byte offset per thread, item i adds an immediate to the slot and
-    // a scalar to the offset.  The tile enters through the base of the buffer resource and six 64-bit lane masks (lanes whose
-    // pixel lies inside the image; the others load at offset -16, which the range check of the buffer load turns into the
-    // zero padding of the convolution).
+    // ---- staging of the raw patch (as conv3x3_wino4p): thread tid < 408 = (patch row r6 < 6, patch column px < 34, k4 = tid & 1)
+    // stages the three pixels (r6 + 6 i, px): one LDS slot and one byte offset per thread; the tile enters through the base of the
+    // buffer resource and three 64-bit lane masks (lanes whose pixel lies outside the image load at offset -16, which the range
+    // check of the buffer load turns into the zero padding of the convolution)
     const bool s_act = tid < NSTG;
     int s_slot;
     unsigned l_off;
-    {
-        const int pix = min(tid, NSTG - 1) >> 1;
-        const int r3 = pix / PW, px = pix - r3 * PW;
-        s_slot = (tid & 1) * RAW_P + r3 * RW + colpos(px);
-        l_off = ((unsigned)(r3 * p.W + px) * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
-    }
-    const int rowblk = 3 * p.W * p.seg[0].pix_stride * 4;        // bytes between the items of a thread
+    const int rowblk = 6 * p.W * p.seg[0].pix_stride * 4;        // bytes between the items of a thread
     typedef unsigned long long u64;
-    u64 mk[6], mk_n[6];                                           // load side's tile / the block's next tile
+    u64 mk[3], mk_n[3];                                           // load side's tile / the block's next tile
     __amdgpu_buffer_rsrc_t r_rsrc0, r_rsrc1;
     int cur_nb, cur_img, cur_ox0, cur_oy0;
     int nxt_nb, nxt_img, nxt_ox0, nxt_oy0;
@@ -140,14 +138,18 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         oy0_ = (bid__ % tiles_y) * TH;                                                              \
         img_ = bid__ / tiles_y;                                                                     \
     } while (0)
+    // lane masks of a tile, from the hardware lane id (no register held between tiles)
 #define W4S_MASKS(ox0_, oy0_, out_)                                                                 \
     do {                                                                                            \
-        const int pix__ = min(tid, NSTG - 1) >> 1;                                                  \
-        const int r3__ = pix__ / PW, px__ = pix__ - r3__ * PW;                                      \
+        int z__ = 0;                                                                                \
+        asm volatile("" : "+v"(z__));                                                               \
+        const int ot__ = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z__)); \
+        const int pix__ = min(ot__, NSTG - 1) >> 1;                                                 \
+        const int r6__ = pix__ / PW, px__ = pix__ - r6__ * PW;                                      \
         const int gx = (ox0_) - 1 + px__;                                                           \
-        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                             \
-            const int gy = (oy0_) - 1 + r3__ + 3 * i;                                               \
-            out_[i] = __builtin_amdgcn_ballot_w64(tid < NSTG && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W); \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
+            const int gy = (oy0_) - 1 + r6__ + 6 * i;                                               \
+            out_[i] = __builtin_amdgcn_ballot_w64(ot__ < NSTG && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W); \
         }                                                                                           \
     } while (0)
 #define W4S_RSRC(img_, ox0_, oy0_)                                                                  \
@@ -157,11 +159,9 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         r_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.seg[1].ptr) + ((long long)(img_) * p.seg[1].img_stride + o__), 0, 0x7fffffff, 0x00020000); \
     } while (0)
     f32x4 sr[3];
-    // The load stream: chunk after chunk of the block's tiles, each chunk in two halves (items 0..2, then 3..5) so that only
-    // three staging registers are live at a time (24 were spilled -- behind vmcnt(0) -- in the first build of this kernel).
-    // W4S_LOAD_STREAM(h): half h of the stream's current chunk -> sr; after the second half of a tile's last chunk the stream
-    // moves on to the block's next tile (and keeps re-reading the very last chunk when there is none: harmless).
-#define W4S_LOAD_STREAM(h_)                                                                         \
+    // next chunk of the load stream -> sr; after a tile's last chunk the stream moves on to the block's next tile (and keeps
+    // re-reading the very last chunk when there is none: harmless)
+#define W4S_LOAD_STREAM()                                                                           \
     do {                                                                                            \
         const bool s1 = lc >= p.seg[0].nchunks;                                                     \
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
@@ -170,216 +170,203 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         if (!(B2F_W4S_ABLATE & 2)) {                                                                \
             _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                         \
                 unsigned vo__;                                                                      \
-                asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(vo__) : "v"(l_off), "s"(mk[3 * (h_) + i])); \
-                sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)vo__, so + (3 * (h_) + i) * rowblk, 0)); \
+                asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(vo__) : "v"(l_off), "s"(mk[i]));     \
+                sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)vo__, so + i * rowblk, 0)); \
             }                                                                                       \
         }                                                                                           \
-        if ((h_) == 1 && ++lc == nchunks) {                                                         \
+        if (++lc == nchunks) {                                                                      \
             if (has_next) {                                                                         \
                 lc = 0;                                                                             \
-                _Pragma("unroll") for (int i = 0; i < 6; ++i) mk[i] = mk_n[i];                      \
+                mk[0] = mk_n[0]; mk[1] = mk_n[1]; mk[2] = mk_n[2];                                  \
                 W4S_RSRC(nxt_img, nxt_ox0, nxt_oy0);                                                \
             } else {                                                                                \
                 lc = nchunks - 1;                                                                   \
             }                                                                                       \
         }                                                                                           \
     } while (0)
-#define W4S_WRITE_RAW(buf_, h_)                                                                     \
+#define W4S_WRITE_RAW(buf_)                                                                         \
     do {                                                                                            \
         f32x4 *r__ = Rb + (buf_) * RAW_F4 + s_slot;                                                 \
-        if (s_act && !(B2F_W4S_ABLATE & 2)) {                                                       \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i) r__[3 * (3 * (h_) + i) * RW] = sr[i];     \
-        }                                                                                           \
+        if (s_act && !(B2F_W4S_ABLATE & 2)) { r__[0] = sr[0]; r__[6 * RW] = sr[1]; r__[12 * RW] = sr[2]; } \
     } while (0)
 
-    // ---- input transform V = B^T d B of a chunk (the arithmetic of b2f_wino4.hip, element for element): lane = (tile = lane
-    // & 31, k4 = lane >> 5), channel pair th = wave & 1 of the k4 group; each wave runs two roles one after the other:
-    //   role A (two rows with shared sub-expressions)   waves 0, 1: rows 1, 2 = (d4 - 4 d2) +- (d3 - 4 d1)
-    //                                                   waves 2, 3: rows 3, 4 = (d4 - d2) +- 2 (d3 - d1)
-    //   role B (one row)                                waves 0, 1: row 0 = 4 d0 + (d4 - 5 d2);  waves 2, 3: row 5 = 4 d1 + (d5 - 5 d3)
-    // 15 slices per chunk: A0..A5 = column s of the 6-wide window (4 row reads, 4 packed ops), A6 / A7 = 6-point column pass
-    // of the first / second produced row + six 8-byte LDS writes, B0..B5 (3 row reads, 2 packed ops), B6 column pass.
-    const int rp = wave >> 1;
+    // ---- input transform V = B^T d B of a chunk: the arithmetic and the roles of b2f_wino4.hip, element for element.
+    // Thread = (tile t = lane & 31, k4 = lane >> 5, channel pair th = wave & 1 of the k4 group's four); wave >> 1 selects the rows:
+    //   waves 0, 1: rows 1, 2   P = d4 - 4 d2, Q = d3 - 4 d1, r1 = P + Q,  r2 = P - Q
+    //   waves 2, 3: rows 3, 4   P = d4 -   d2, Q = d3 -   d1, r3 = P + 2Q, r4 = P - 2Q
+    //   waves 4, 5: row 0       P = d4 - 5 d2, Q = d0,        r0 = P + 4Q
+    //   waves 6, 7: row 5       P = d5 - 5 d3, Q = d1,        r5 = P + 4Q
+    // one instruction stream  P = fma(ca, x1, x2), Q = fma(cb, x3, x4), rA = fma(cs, Q, P), rB = fma(-cs, Q, P)  with wave-uniform
+    // rows and coefficients, then the 6-point column pass of each produced row.  Slice s < 6: column s of the 6-wide window;
+    // slice 6 / 7: column pass + LDS writes of the first / second produced row.
+    const int t_role = wave >> 1;
     const int th = wave & 1;
-    const float a_ca = rp ? -1.f : -4.f, a_cs = rp ? 2.f : 1.f;  // role A: P = fma(ca, d2, d4), Q = fma(ca, d1, d3), r = P +- cs Q
-    const int a_orow = rp ? 3 : 1;
-    const int b_r1 = rp ? 3 : 2, b_r2 = rp ? 5 : 4, b_r3 = rp ? 1 : 0, b_orow = rp ? 5 : 0;   // role B: P = fma(-5, d[r1], d[r2]), r = fma(4, d[r3], P)
-    const int t_base = half * RAW_P + (4 * (m >> 3)) * RW + (m & 7);
-    const int ta_row[4] = {t_base + 2 * RW, t_base + 4 * RW, t_base + 1 * RW, t_base + 3 * RW};
-    const int tb_row[3] = {t_base + b_r1 * RW, t_base + b_r2 * RW, t_base + b_r3 * RW};
-    const int ta_dst = (a_orow * 6 * 2 + half) * 32 + m;        // float4 index of V[xi = 6 row][k4][tile]; xi + 1 -> + 64, next row -> + 384
-    const int tb_dst = (b_orow * 6 * 2 + half) * 32 + m;
-    f32x4 RA[6];                                                // role A: (row a | row b) of tile column j, one channel pair
-    f32x2 RB[6];
-    f32x2 da[2][4], db[4][3];                                   // rows read one step ahead of their use
-#define W4S_TA_READ(s_, rbuf_, k_)                                                                  \
+    int rx1, rx2, rx3, rx4, t_orow;
+    float t_ca, t_cb, t_cs;
+    switch (t_role) {
+    case 0: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -4.f; t_cb = -4.f; t_cs = 1.f; t_orow = 1; break;
+    case 1: rx1 = 2; rx2 = 4; rx3 = 1; rx4 = 3; t_ca = -1.f; t_cb = -1.f; t_cs = 2.f; t_orow = 3; break;
+    case 2: rx1 = 2; rx2 = 4; rx3 = 0; rx4 = 0; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 0; break;
+    default: rx1 = 3; rx2 = 5; rx3 = 1; rx4 = 1; t_ca = -5.f; t_cb = 0.f; t_cs = 4.f; t_orow = 5; break;
+    }
+    const bool t_two = t_role < 2;
+    int t_row[4], t_dst;
+    f32x4 R[6], d[2];
+#define W4S_T_READ(s_, rbuf_)                                                                       \
     do {                                                                                            \
-        const f32x2 *rp__ = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4 + colpos(s_)) + th; \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) da[k_][r] = rp__[2 * ta_row[r]];             \
+        if ((s_) < 6 && !(B2F_W4S_ABLATE & 1)) {                                                    \
+            const f32x2 *rp = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4 + colpos(s_)) + th; \
+            const f32x2 x1 = rp[2 * t_row[0]], x2 = rp[2 * t_row[1]], x3 = rp[2 * t_row[2]], x4 = rp[2 * t_row[3]]; \
+            d[0] = __builtin_shufflevector(x1, x2, 0, 1, 2, 3);                                     \
+            d[1] = __builtin_shufflevector(x3, x4, 0, 1, 2, 3);                                     \
+        }                                                                                           \
     } while (0)
-#define W4S_TA_FMA(s_, k_)                                                                          \
+    // packed ops as inline asm (pins the slice where it stands; the bf16 MFMA does co-issue with them)
+#define W4S_T_FMA(s_, vbuf_)                                                                        \
     do {                                                                                            \
-        const f32x2 ca2 = {a_ca, a_ca}, cs2 = {a_cs, a_cs};                                         \
-        const f32x2 P = W4S_FMA(ca2, da[k_][0], da[k_][1]), Q = W4S_FMA(ca2, da[k_][2], da[k_][3]); \
-        const f32x2 oa = W4S_FMA(cs2, Q, P), ob = W4S_FMA(-cs2, Q, P);                              \
-        RA[s_] = __builtin_shufflevector(oa, ob, 0, 1, 2, 3);                                       \
+        if (B2F_W4S_ABLATE & 1) {                                                                   \
+        } else if ((s_) < 6) {                                                                      \
+            const f32x2 ca2 = {t_ca, t_ca}, cb2 = {t_cb, t_cb}, cs2 = {t_cs, t_cs}, cn2 = {-t_cs, -t_cs}; \
+            const f32x2 x1 = __builtin_shufflevector(d[0], d[0], 0, 1), x2 = __builtin_shufflevector(d[0], d[0], 2, 3); \
+            const f32x2 x3 = __builtin_shufflevector(d[1], d[1], 0, 1), x4 = __builtin_shufflevector(d[1], d[1], 2, 3); \
+            /* (scalar fp32 FMAs, same values as the fp32 kernel's packed ones) */                  \
+            const f32x2 P = {W4S_F(ca2[0], x1[0], x2[0]), W4S_F(ca2[1], x1[1], x2[1])};             \
+            const f32x2 Q = {W4S_F(cb2[0], x3[0], x4[0]), W4S_F(cb2[1], x3[1], x4[1])};             \
+            const f32x2 oa = {W4S_F(cs2[0], Q[0], P[0]), W4S_F(cs2[1], Q[1], P[1])};                \
+            const f32x2 ob = {W4S_F(cn2[0], Q[0], P[0]), W4S_F(cn2[1], Q[1], P[1])};                \
+            R[(s_) < 6 ? (s_) : 0] = __builtin_shufflevector(oa, ob, 0, 1, 2, 3);                   \
+        } else if ((s_) == 6) {                                                                     \
+            W4S_T_COLPASS(0, (vbuf_));                                                              \
+        } else if (t_two) {                                                                         \
+            W4S_T_COLPASS(1, (vbuf_));                                                              \
+        }                                                                                           \
     } while (0)
-#define W4S_TB_READ(s_, rbuf_, k_)                                                                  \
-    do {                                                                                            \
-        const f32x2 *rp__ = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4 + colpos(s_)) + th; \
-        _Pragma("unroll") for (int r = 0; r < 3; ++r) db[k_][r] = rp__[2 * tb_row[r]];             \
-    } while (0)
-#define W4S_TB_FMA(s_, k_)                                                                          \
-    do {                                                                                            \
-        const f32x2 k5 = {-5.f, -5.f}, k4c = {4.f, 4.f};                                            \
-        const f32x2 P = W4S_FMA(k5, db[k_][0], db[k_][1]);                                          \
-        RB[s_] = W4S_FMA(k4c, db[k_][2], P);                                                        \
-    } while (0)
-    // column pass of one produced row: V[a][.] = r B (12 packed ops), six 8-byte LDS writes
-#define W4S_COLPASS(r0, r1, r2, r3, r4, r5, dst_, vbuf_)                                            \
+#define W4S_T_COLPASS(hh_, vbuf_)                                                                   \
     do {                                                                                            \
         const f32x2 k4v = {4.f, 4.f}, k5v = {-5.f, -5.f}, km4 = {-4.f, -4.f}, k2v = {2.f, 2.f}, km2 = {-2.f, -2.f}; \
-        const f32x2 t0 = W4S_FMA(k5v, (r2), W4S_FMA(k4v, (r0), (r4)));                              \
-        const f32x2 pq = W4S_FMA(km4, (r2), (r4)), qq = W4S_FMA(km4, (r1), (r3));                   \
-        const f32x2 uu = (r4) - (r2), vv = (r3) - (r1);                                             \
-        const f32x2 t1 = W4S_FMA(k5v, (r3), W4S_FMA(k4v, (r1), (r5)));                              \
-        const f32x2 o1 = pq + qq, o2 = pq - qq;                                                     \
-        const f32x2 o3 = W4S_FMA(k2v, vv, uu), o4 = W4S_FMA(km2, vv, uu);                           \
-        f32x2 *v__ = reinterpret_cast<f32x2 *>(Vb + (vbuf_) * VSTRIDE + (dst_)) + th;               \
-        v__[0] = t0; v__[2 * 64] = o1; v__[2 * 128] = o2; v__[2 * 192] = o3; v__[2 * 256] = o4; v__[2 * 320] = t1; \
-    } while (0)
-#define W4S_LO(x_) __builtin_shufflevector((x_), (x_), 0, 1)
-#define W4S_HI(x_) __builtin_shufflevector((x_), (x_), 2, 3)
-#define W4S_TA_COL(hh_, vbuf_)                                                                      \
-    do {                                                                                            \
-        if ((hh_) == 0) W4S_COLPASS(W4S_LO(RA[0]), W4S_LO(RA[1]), W4S_LO(RA[2]), W4S_LO(RA[3]), W4S_LO(RA[4]), W4S_LO(RA[5]), ta_dst, (vbuf_)); \
-        else W4S_COLPASS(W4S_HI(RA[0]), W4S_HI(RA[1]), W4S_HI(RA[2]), W4S_HI(RA[3]), W4S_HI(RA[4]), W4S_HI(RA[5]), ta_dst + 384, (vbuf_)); \
-    } while (0)
-#define W4S_TB_COL(vbuf_) W4S_COLPASS(RB[0], RB[1], RB[2], RB[3], RB[4], RB[5], tb_dst, (vbuf_))
-    // The transform of chunk k as a schedule over the xi steps of the two iterations before it (rd = raw buffer that holds
-    // chunk k, vb = V buffer it goes to).  Reads are issued one step before the slice that uses them:
-    //   iteration k - 2, after the barrier of step 6:  reads A0 A1 | step 7: A0 A1, reads A2 A3 | step 8: A2 A3, reads A4 A5
-    //   iteration k - 1:  step 0: A4 A5 | 1: A6, reads B0..B3 | 2: A7 | 3: B0..B3, reads B4 B5 | 4: B4 B5 | 5: B6 | 6: raw write, barrier
-#define W4S_TR_EARLY(x_, rd_)                                                                       \
-    do {                                                                                            \
-        if (!(B2F_W4S_ABLATE & 1)) {                                                                \
-            if ((x_) == 6) { W4S_TA_READ(0, rd_, 0); W4S_TA_READ(1, rd_, 1); }                      \
-            if ((x_) == 7) { W4S_TA_FMA(0, 0); W4S_TA_FMA(1, 1); W4S_TA_READ(2, rd_, 0); W4S_TA_READ(3, rd_, 1); } \
-            if ((x_) == 8) { W4S_TA_FMA(2, 0); W4S_TA_FMA(3, 1); W4S_TA_READ(4, rd_, 0); W4S_TA_READ(5, rd_, 1); } \
+        f32x2 r0 = (hh_) ? __builtin_shufflevector(R[0], R[0], 2, 3) : __builtin_shufflevector(R[0], R[0], 0, 1); \
+        f32x2 r1 = (hh_) ? __builtin_shufflevector(R[1], R[1], 2, 3) : __builtin_shufflevector(R[1], R[1], 0, 1); \
+        f32x2 r2 = (hh_) ? __builtin_shufflevector(R[2], R[2], 2, 3) : __builtin_shufflevector(R[2], R[2], 0, 1); \
+        f32x2 r3 = (hh_) ? __builtin_shufflevector(R[3], R[3], 2, 3) : __builtin_shufflevector(R[3], R[3], 0, 1); \
+        f32x2 r4 = (hh_) ? __builtin_shufflevector(R[4], R[4], 2, 3) : __builtin_shufflevector(R[4], R[4], 0, 1); \
+        f32x2 r5 = (hh_) ? __builtin_shufflevector(R[5], R[5], 2, 3) : __builtin_shufflevector(R[5], R[5], 0, 1); \
+        f32x2 t0, t1, pq, qq, uu, vv, o1, o2, o3, o4;                                               \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                             \
+            t0[e] = W4S_F(k5v[e], r2[e], W4S_F(k4v[e], r0[e], r4[e]));                              \
+            pq[e] = W4S_F(km4[e], r2[e], r4[e]); qq[e] = W4S_F(km4[e], r1[e], r3[e]);               \
+            uu[e] = r4[e] - r2[e]; vv[e] = r3[e] - r1[e];                                           \
+            t1[e] = W4S_F(k5v[e], r3[e], W4S_F(k4v[e], r1[e], r5[e]));                              \
+            o1[e] = pq[e] + qq[e]; o2[e] = pq[e] - qq[e];                                           \
+            o3[e] = W4S_F(k2v[e], vv[e], uu[e]); o4[e] = W4S_F(km2[e], vv[e], uu[e]);               \
         }                                                                                           \
-    } while (0)
-#define W4S_TR_LATE(x_, rd_, vb_)                                                                   \
-    do {                                                                                            \
-        if (!(B2F_W4S_ABLATE & 1)) {                                                                \
-            if ((x_) == 0) { W4S_TA_FMA(4, 0); W4S_TA_FMA(5, 1); }                                  \
-            if ((x_) == 1) { W4S_TA_COL(0, vb_); W4S_TB_READ(0, rd_, 0); W4S_TB_READ(1, rd_, 1); W4S_TB_READ(2, rd_, 2); W4S_TB_READ(3, rd_, 3); } \
-            if ((x_) == 2) { W4S_TA_COL(1, vb_); }                                                  \
-            if ((x_) == 3) { W4S_TB_FMA(0, 0); W4S_TB_FMA(1, 1); W4S_TB_FMA(2, 2); W4S_TB_FMA(3, 3); W4S_TB_READ(4, rd_, 0); W4S_TB_READ(5, rd_, 1); } \
-            if ((x_) == 4) { W4S_TB_FMA(4, 0); W4S_TB_FMA(5, 1); }                                  \
-            if ((x_) == 5) { W4S_TB_COL(vb_); }                                                     \
-        }                                                                                           \
+        f32x2 *v = reinterpret_cast<f32x2 *>(Vb + (vbuf_) * VSTRIDE + t_dst + 384 * (hh_)) + th;    \
+        v[0] = t0; v[2 * 64] = o1; v[2 * 128] = o2; v[2 * 192] = o3; v[2 * 256] = o4; v[2 * 320] = t1; \
     } while (0)
 
-    // ---- GEMM side: wave w owns xi = 9 w + x, x = 0..8, for both N tiles ----
-    f32x16 acc[9][2];
-    const int a_off = (9 * wave * 2 + half) * 32 + m;            // float4 index of V[xi = 9w][k4 = half][tile m]; xi + 1 -> + 64
-    const unsigned b4_off = ((9 * wave * 2 + half) * 64 + m) * 16u;      // bytes: (Um Um Uh Uh) of [xi = 9w][k4][co m]; xi + 1 -> + 2048, N tile 1 -> + 512
-    const unsigned b2_off = U4_BYTES + ((9 * wave * 2 + half) * 64 + m) * 8u;   // (Ul Ul); xi + 1 -> + 1024, N tile 1 -> + 256
-    f32x4 avf[3];                                                 // fp32 A values, read two steps ahead
-    unsigned wa[2][6];                                            // split A windows, one step ahead
-    u32x4 bq[3][2];                                               // B ring: three slots, two steps (>= 12 MFMAs) ahead; 9 steps per chunk,
-    u32x2 bl[3][2];                                               // so step x always uses slot x % 3
+    // ---- GEMM side: wave (g, n) owns xi = 9 g + x, x = 0..8, of N tile n ----
+    f32x16 acc[9];
+    int a_off;                                                    // float4 index of V[xi = 9g][k4 = lane >> 5][tile lane & 31]; xi + 1 -> + 64
+    unsigned b4_off, b2_off;                                      // bytes: (Um Um Uh Uh) of [xi = 9g][k4][co]; xi + 1 -> + 2048 | (Ul Ul): xi + 1 -> + 1024
+    f32x4 av[3];                                                  // fp32 A values, read one step ahead
+    unsigned wa[6];                                               // the step's split A window
+#ifndef W4S_LA
+#define W4S_LA 3                                                  // B operands this many xi steps ahead (ring of 6 slots: the pattern repeats every two chunks)
+#endif
+    u32x4 bq[6];
+    u32x2 bl[6];
     __amdgpu_buffer_rsrc_t w_rsrc;
 #define W4S_LOAD_U(slot_, c_, x_)                                                                   \
     do {                                                                                            \
         if (!(B2F_W4S_ABLATE & 4)) {                                                                \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
-                bq[slot_][n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b4_off, (int)((c_) * UC_BYTES + (x_) * 2048 + n * 512), 0)); \
-                bl[slot_][n] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)b2_off, (int)((c_) * UC_BYTES + (x_) * 1024 + n * 256), 0)); \
-            }                                                                                       \
+            bq[slot_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b4_off, (int)((c_) * UC_BYTES + (x_) * 2048), 0)); \
+            bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)b2_off, (int)((c_) * UC_BYTES + (x_) * 1024), 0)); \
         }                                                                                           \
     } while (0)
-    // 18 accumulators = 288 registers, the accumulator file holds 256: the ninth xi of a wave accumulates in ordinary VGPRs
-    // (the "+v" form below); left to itself the compiler keeps swapping two accumulators through the accumulator file
-#define W4S_MFMA_V(acc_, a_, b_) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc_) : "v"(a_), "v"(b_))
-#define W4S_MFMA(x_, par_, slot_)                                                                   \
+#define W4S_MFMA(x_, slot_)                                                                         \
     do {                                                                                            \
-        if (!(B2F_W4S_ABLATE & 8) && (x_) == 8 && B2F_W4S_ASM8) {                                   \
-            const u32x4 a_mh = {wa[par_][0], wa[par_][1], wa[par_][2], wa[par_][3]};                \
-            const u32x4 a_hl = {wa[par_][2], wa[par_][3], wa[par_][4], wa[par_][5]};                \
-            const u32x4 b_hl0 = {bq[slot_][0][2], bq[slot_][0][3], bl[slot_][0][0], bl[slot_][0][1]}; \
-            const u32x4 b_hl1 = {bq[slot_][1][2], bq[slot_][1][3], bl[slot_][1][0], bl[slot_][1][1]}; \
-            W4S_MFMA_V(acc[8][0], a_mh, bq[slot_][0]); W4S_MFMA_V(acc[8][1], a_mh, bq[slot_][1]);   \
-            W4S_MFMA_V(acc[8][0], a_hl, bq[slot_][0]); W4S_MFMA_V(acc[8][1], a_hl, bq[slot_][1]);   \
-            W4S_MFMA_V(acc[8][0], a_mh, b_hl0); W4S_MFMA_V(acc[8][1], a_mh, b_hl1);                 \
-        } else if (!(B2F_W4S_ABLATE & 8)) {                                                         \
-            const u32x4 a_mh = {wa[par_][0], wa[par_][1], wa[par_][2], wa[par_][3]};                \
-            const u32x4 a_hl = {wa[par_][2], wa[par_][3], wa[par_][4], wa[par_][5]};                \
-            const u32x4 b_hl0 = {bq[slot_][0][2], bq[slot_][0][3], bl[slot_][0][0], bl[slot_][0][1]}; \
-            const u32x4 b_hl1 = {bq[slot_][1][2], bq[slot_][1][3], bl[slot_][1][0], bl[slot_][1][1]}; \
-            acc[x_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, bq[slot_][0]), acc[x_][0], 0, 0, 0); \
-            acc[x_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, bq[slot_][1]), acc[x_][1], 0, 0, 0); \
-            acc[x_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq[slot_][0]), acc[x_][0], 0, 0, 0); \
-            acc[x_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq[slot_][1]), acc[x_][1], 0, 0, 0); \
-            acc[x_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl0), acc[x_][0], 0, 0, 0); \
-            acc[x_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl1), acc[x_][1], 0, 0, 0); \
+        if (!(B2F_W4S_ABLATE & 16)) w4s_split(av[(x_) % 3], wa);                                    \
+        else { _Pragma("unroll") for (int k = 0; k < 6; ++k) wa[k] = __builtin_bit_cast(unsigned, av[(x_) % 3][k & 3]); } \
+        if (!(B2F_W4S_ABLATE & 8)) {                                                                \
+            u32x4 a_mh = {wa[0], wa[1], wa[2], wa[3]};                                              \
+            u32x4 a_hl = {wa[2], wa[3], wa[4], wa[5]};                                              \
+            u32x4 b_hl = {bq[slot_][2], bq[slot_][3], bl[slot_][0], bl[slot_][1]};                  \
+            /* the three MFMAs of a step chain through one accumulator: strictly back to back (the pipe forwards the */ \
+            /* accumulator; ONE other instruction between two of them costs ~43 cycles, MI355X_MICROARCH.md) -- the */ \
+            /* operand copies are made first, the partner wave of the SIMD issues its VALU work meanwhile */ \
+            asm volatile("" : "+v"(a_mh), "+v"(a_hl), "+v"(b_hl));                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, bq[slot_]), acc[x_], 0, 0, 0); \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq[slot_]), acc[x_], 0, 0, 0); \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl), acc[x_], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
     } while (0)
-#define W4S_SPLIT(src_, par_)                                                                       \
+    // the per-lane constants of the main loop, recomputed from the hardware lane id at the start of every tile: held across the
+    // output stage they would be spilled, and a spill reload waits (vmcnt counts in order) for the output stores
+#define W4S_LANE_CONSTANTS()                                                                        \
     do {                                                                                            \
-        if (!(B2F_W4S_ABLATE & 16)) w4s_split(avf[src_], wa[par_]);                                 \
-        else { _Pragma("unroll") for (int k = 0; k < 6; ++k) wa[par_][k] = __builtin_bit_cast(unsigned, avf[src_][k & 3]); } \
+        int lz = 0;                                                                                 \
+        asm volatile("" : "+v"(lz));                                                                \
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)lz)); \
+        const int lm = ln & 31, lh = ln >> 5, ltid = wave * 64 + ln;                                \
+        const int tb = lh * RAW_P + (4 * (lm >> 3)) * RW + (lm & 7);                                \
+        t_row[0] = tb + rx1 * RW; t_row[1] = tb + rx2 * RW; t_row[2] = tb + rx3 * RW; t_row[3] = tb + rx4 * RW; \
+        t_dst = (t_orow * 6 * 2 + lh) * 32 + lm;                                                    \
+        a_off = (9 * g * 2 + lh) * 32 + lm;                                                         \
+        b4_off = ((9 * g * 2 + lh) * 64 + n * 32 + lm) * 16u;                                       \
+        b2_off = U4_BYTES + ((9 * g * 2 + lh) * 64 + n * 32 + lm) * 8u;                             \
+        const int pix = min(ltid, NSTG - 1) >> 1;                                                   \
+        const int r6 = pix / PW, px = pix - r6 * PW;                                                \
+        s_slot = (ltid & 1) * RAW_P + r6 * RW + colpos(px);                                         \
+        l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (ltid & 1) * 4) * 4u;  \
     } while (0)
 
-    // ---- first tile: prologue ----
+    // ---- first tile: prologue as in the fp32 kernel ----
+    W4S_LANE_CONSTANTS();
     W4S_DECODE((int)blockIdx.x, cur_nb, cur_img, cur_ox0, cur_oy0);
     W4S_MASKS(cur_ox0, cur_oy0, mk);
     W4S_RSRC(cur_img, cur_ox0, cur_oy0);
     has_next = false;                                                           // no switch inside the prologue (nchunks >= 4)
     nxt_nb = cur_nb; nxt_img = cur_img; nxt_ox0 = cur_ox0; nxt_oy0 = cur_oy0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) mk_n[i] = mk[i];
+    mk_n[0] = mk[0]; mk_n[1] = mk[1]; mk_n[2] = mk[2];
     int par = 0;                                                                // parity (V / raw buffer) of the tile's chunk 0
     int v_cur = blockIdx.x;
-    W4S_LOAD_STREAM(0); W4S_WRITE_RAW(0, 0); W4S_LOAD_STREAM(1); W4S_WRITE_RAW(0, 1);     // chunk 0
-    W4S_LOAD_STREAM(0); W4S_WRITE_RAW(1, 0); W4S_LOAD_STREAM(1); W4S_WRITE_RAW(1, 1);     // chunk 1
-    W4S_LOAD_STREAM(0);                      // first half of chunk 2, stays in flight
+    W4S_LOAD_STREAM(); W4S_WRITE_RAW(0);     // chunk 0
+    W4S_LOAD_STREAM(); W4S_WRITE_RAW(1);     // chunk 1
+    W4S_LOAD_STREAM();                       // chunk 2, stays in flight
     __syncthreads();
-    // Tr(0) -> V[0] in one go, then the early slices of Tr(1)
 #pragma unroll
-    for (int x = 6; x < 9; ++x) W4S_TR_EARLY(x, 0);
-#pragma unroll
-    for (int x = 0; x < 6; ++x) W4S_TR_LATE(x, 0, 0);
-#pragma unroll
-    for (int x = 6; x < 9; ++x) W4S_TR_EARLY(x, 1);
+    for (int s = 0; s < 8; ++s) { W4S_T_READ(s, 0); W4S_T_FMA(s, 0); }
     __syncthreads();
 
     w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)cur_nb * nchunks * UC_BYTES), 0, 0x7fffffff, 0x00020000);
-    W4S_LOAD_U(0, 0, 0); W4S_LOAD_U(1, 0, 1);
+#define W4S_PRELOAD_U() do { _Pragma("unroll") for (int x = 0; x < W4S_LA; ++x) W4S_LOAD_U(x, 0, x); } while (0)
+    W4S_PRELOAD_U();
     for (;;) {
-        // ---- start of a tile: V[par] holds Tr(0), raw buffer par ^ 1 holds chunk 1 with the early slices of Tr(1) done (RA[0..3],
-        // reads of A4 A5 in flight), the first half of chunk 2 is in flight in sr, the first two B operands are in flight ----
+        // ---- start of a tile: V[par] holds Tr(0), raw buffer par ^ 1 holds chunk 1, chunk 2 is in flight in sr, the first two
+        // B operands are in flight (issued under the last output pass of the previous tile) ----
         has_next = v_cur + G < total;
         if (has_next) {
             W4S_DECODE(v_cur + G, nxt_nb, nxt_img, nxt_ox0, nxt_oy0);
             W4S_MASKS(nxt_ox0, nxt_oy0, mk_n);
         }
-        avf[0] = Vb[par * VSTRIDE + a_off];
-        avf[1] = Vb[par * VSTRIDE + a_off + 64];
-        W4S_SPLIT(0, 0);
+        W4S_LANE_CONSTANTS();
+        W4S_T_READ(0, par ^ 1); W4S_T_FMA(0, 0);
+        W4S_T_READ(1, par ^ 1); W4S_T_FMA(1, 0);
+        W4S_T_READ(2, par ^ 1);
+        av[0] = Vb[par * VSTRIDE + a_off];
+        av[1] = Vb[par * VSTRIDE + a_off + 64];
 #pragma unroll
         for (int x = 0; x < 9; ++x)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-        // One chunk of the software pipeline; PH_ = parity of the A window at step 0 (9 steps per chunk: the pattern repeats
-        // every two chunks, the loop below is unrolled by two; an odd last chunk reuses phase 0), LAST_ = the tile's last chunk
-        // (no B operands of a following chunk: they are fetched under the last output pass).
-        //   step x: B of step x + 2 | fp32 A of step x + 2 | six MFMAs of step x, the split of step x + 1 and the transform
-        //   slices of this step interleaved by the scheduler | (step 6: raw(c + 2) -> LDS, barrier, stream load of raw(c + 3))
+        // One chunk of the software pipeline (the fp32 kernel's, with the split + three bf16 MFMAs in place of four fp32 MFMAs):
+        //   iteration c, xi steps 0..5 : B of step x + 2, fp32 A of step x + 1; split + MFMAs of step x; slices 2..7 of Tr(c+1)
+        //                xi step  6    : raw(c+2) -> LDS, A of xi 7, 8 fetched, BARRIER
+        //                xi steps 7, 8 : A of xi 0, 1 of chunk c+1, slices 0, 1 of Tr(c+2); global loads of raw(c+3)
+        // LAST_ = the tile's last chunk: no B operands of a following chunk (fetched under the last output pass instead)
 #define W4S_CHUNK(PH_, c_, LAST_)                                                                   \
     do {                                                                                            \
         const int c = (c_);                                                                         \
@@ -387,25 +374,29 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         const f32x4 *Vc = Vb + pc * VSTRIDE + a_off;                                                \
         const f32x4 *Vn = Vb + (pc ^ 1) * VSTRIDE + a_off;                                          \
         _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
-            if (x + 2 < 9) W4S_LOAD_U((x + 2) % 3, c, x + 2);                                       \
-            else if (!(LAST_)) W4S_LOAD_U((x + 2) % 3, c + 1, x + 2 - 9);                           \
-            if (x <= 6) avf[(x + 2) % 3] = Vc[(x + 2) * 64];   /* every read of V[pc] is issued before the barrier of step 6 */ \
-            else avf[(x + 2) % 3] = Vn[(x - 7) * 64];          /* steps 0, 1 of the next chunk, after it */ \
-            W4S_MFMA(x, (9 * (PH_) + x) & 1, x % 3);                                                \
-            W4S_SPLIT((x + 1) % 3, (9 * (PH_) + x + 1) & 1);                                        \
-            if (x < 6) W4S_TR_LATE(x, pc ^ 1, pc ^ 1);                                              \
-            /* raw(c + 2) -> raw buffer pc (free since the barrier of the previous iteration): first half (in flight since */ \
-            /* that barrier) at step 1, then the second half is loaded and written at step 6, before this barrier */ \
-            if (x == 1) { W4S_WRITE_RAW(pc, 0); W4S_LOAD_STREAM(1); }                               \
-            if (x == 6) {                                                                           \
-                W4S_WRITE_RAW(pc, 1);                                                               \
+            if (x + W4S_LA < 9) W4S_LOAD_U((9 * (PH_) + x + W4S_LA) % 6, c, x + W4S_LA);            \
+            else if (!(LAST_)) W4S_LOAD_U((9 * (PH_) + x + W4S_LA) % 6, c + 1, x + W4S_LA - 9);     \
+            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                               \
+            if (x == 6) av[8 % 3] = Vc[8 * 64];                                                     \
+            if (x == 7) av[0] = Vn[0];                                                              \
+            if (x == 8) av[1] = Vn[64];                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            W4S_MFMA(x, (9 * (PH_) + x) % 6);                                                       \
+            if (x < 6) {                                                                            \
+                W4S_T_FMA(x + 2, pc ^ 1);                                                           \
+                if (x + 3 < 8) W4S_T_READ(x + 3, pc ^ 1);                                           \
+            } else if (x == 6) {                                                                    \
+                W4S_WRITE_RAW(pc);                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 __syncthreads();                                                                    \
-                __builtin_amdgcn_sched_barrier(0);                                                  \
-                if (!(LAST_)) W4S_LOAD_STREAM(0);  /* the last chunk's is issued in the output stage */ \
+                W4S_T_READ(0, pc);                                                                  \
+                if (!(LAST_)) W4S_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
+            } else if (x == 7) {                                                                    \
+                W4S_T_FMA(0, 0); W4S_T_READ(1, pc);                                                 \
+            } else {                                                                                \
+                W4S_T_FMA(1, 0); W4S_T_READ(2, pc);                                                 \
             }                                                                                       \
-            if (x >= 6) W4S_TR_EARLY(x, pc);                                                        \
-            __builtin_amdgcn_sched_barrier(0);   /* the scheduler interleaves inside a step, never across steps */ \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
     } while (0)
         {
@@ -421,17 +412,20 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         }
 #undef W4S_CHUNK
 
-        // ---- output: four passes (tile rows) through the exchange buffer = dead V buffer + gap (as conv3x3_wino4p<2>; a wave
-        // dumps its nine xi planes for both N tiles, a thread transforms two items = (tile column, output column j, 4 channels)) ----
+        // ---- output: four passes (tile rows) through the exchange buffer = dead V buffer + gap, exactly as conv3x3_wino4p<2> ----
         const int pl = (par + nchunks - 1) & 1;                                 // V[pl] is dead, V[pl ^ 1] holds the next tile's Tr(0)
-        unsigned dump_rel[4][2];
+        int oz = 0;
+        asm volatile("" : "+v"(oz));
+        const int olane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)oz));
+        const int om = olane & 31, ohalf = olane >> 5;
+        unsigned dump_rel[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int t8 = e + 4 * half;                                        // tile column inside the tile row
-#pragma unroll
-            for (int n = 0; n < 2; ++n) dump_rel[e][n] = 4u * (unsigned)((9 * wave * 8 + t8) * 64 + ((n * 32 + m) ^ (t8 << 3)));
+            const int t8 = e + 4 * ohalf;                                       // tile column inside the tile row
+            dump_rel[e] = 4u * (unsigned)((9 * g * 8 + t8) * 64 + ((n * 32 + om) ^ (t8 << 3)));
         }
-        const int o_tx = lane >> 3, o_j = (lane >> 1) & 3;
+        const int o_tx = olane >> 3, o_j = (olane >> 1) & 3, o_cq = 2 * wave + (olane & 1);
+        const int o_rel = o_tx * 64 + ((4 * o_cq) ^ (o_tx << 3));               // float index inside a xi plane (512 floats)
         const float o_sg = (o_j & 1) ? -1.f : 1.f;
         const float o_kq = o_j == 0 ? 1.f : o_j == 1 ? 2.f : o_j == 2 ? 4.f : 8.f;
         const float o_k0 = o_j == 0 ? 1.f : 0.f, o_k3 = o_j == 3 ? 1.f : 0.f;
@@ -439,40 +433,41 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
         float *X = reinterpret_cast<float *>(Vb + pl * V_F4);
         const unsigned xbase = static_cast<unsigned>(reinterpret_cast<size_t>(X));
         float *ob = p.out + (size_t)cur_img * p.out_img_stride;
-        const int ox = cur_ox0 + 4 * o_tx + o_j;
-        f32x4 bias[2];
-        const float *xa[2];
-        float *obase[2];
-        bool col_ok[2];
+        const int co0 = cur_nb * 64 + 4 * o_cq;
+        // bias of this wave's 8 channels through the scalar cache (a vector load here would wait, in order, behind the
+        // raw-patch loads of the next tile that are in flight)
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat *bp = (cfloat *)(p.bias + cur_nb * 64 + 8 * wave);
+        float bb[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o_cq = 2 * (2 * wave + i) + (lane & 1);
-            const int co0 = cur_nb * 64 + 4 * o_cq;
-            bias[i] = *reinterpret_cast<const f32x4 *>(p.bias + co0);
-            xa[i] = X + o_tx * 64 + ((4 * o_cq) ^ (o_tx << 3));
-            col_ok[i] = co0 < p.cout;
-            obase[i] = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(cur_oy0 * p.Wo + ox) * p.out_pix_stride + (co0 & 7);
+        for (int k = 0; k < 8; ++k) {
+            bb[k] = bp[k];
+            asm volatile("" : "+s"(bb[k]));       // keeps the eight loads scalar
         }
+        const f32x4 bias = (olane & 1) ? f32x4{bb[4], bb[5], bb[6], bb[7]} : f32x4{bb[0], bb[1], bb[2], bb[3]};
+        const bool col_ok = co0 < p.cout;
+        const int ox = cur_ox0 + 4 * o_tx + o_j;
+        float *obase = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(cur_oy0 * p.Wo + ox) * p.out_pix_stride + (co0 & 7);
+        const float *xa = X + o_rel;
 #define W4S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define W4S_PASS(q_, EXTRA_)                                                                        \
     do {                                                                                            \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                         \
-                const unsigned da__ = xbase + dump_rel[e][n];                                       \
-                _Pragma("unroll") for (int x = 0; x < 8; x += 2)                                    \
-                    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"               \
-                                 :: "v"(da__), "a"(acc[x][n][4 * (q_) + e]), "a"(acc[x + 1][n][4 * (q_) + e]), "n"(x * 8), "n"((x + 1) * 8) : "memory"); \
-                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(da__), "v"(acc[8][n][4 * (q_) + e]), "n"(8 * 8 * 256) : "memory"); \
-            }                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+            const unsigned da = xbase + dump_rel[e];                                                \
+            _Pragma("unroll") for (int x = 0; x < 8; x += 2)                                        \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"                   \
+                             :: "v"(da), W4S_ACC_REG(acc[x][4 * (q_) + e]), W4S_ACC_REG(acc[x + 1][4 * (q_) + e]), "n"(x * 8), "n"((x + 1) * 8) : "memory"); \
+            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(da), W4S_ACC_REG(acc[8][4 * (q_) + e]), "n"(8 * 8 * 256) : "memory"); \
+        }                                                                                           \
         W4S_LDS_BARRIER();                                                                          \
         EXTRA_                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+        {                                                                                           \
             const f32x4 sg4 = {o_sg, o_sg, o_sg, o_sg}, kq4 = {o_kq, o_kq, o_kq, o_kq};             \
             const f32x4 k04 = {o_k0, o_k0, o_k0, o_k0}, k34 = {o_k3, o_k3, o_k3, o_k3};             \
             const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f}; \
             f32x4 T[6];                                                                             \
             _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                         \
-                const float *xr6 = xa[i] + (6 * a) * 512;                                           \
+                const float *xr6 = xa + (6 * a) * 512;                                              \
                 const f32x4 m1 = *reinterpret_cast<const f32x4 *>(xr6 + 1 * 512), m2 = *reinterpret_cast<const f32x4 *>(xr6 + 2 * 512); \
                 const f32x4 m3 = *reinterpret_cast<const f32x4 *>(xr6 + 3 * 512), m4 = *reinterpret_cast<const f32x4 *>(xr6 + 4 * 512); \
                 const f32x4 me = *reinterpret_cast<const f32x4 *>(xr6 + o_xe);                      \
@@ -488,24 +483,24 @@ __global__ __launch_bounds__(256) void conv3x3_wino4s(const ConvLaunch p)
             y[2] = W4S_FMA(k4, s2, s1);                                                             \
             y[3] = W4S_FMA(k8, d2, d1) + T[5];                                                      \
             const int oy = cur_oy0 + 4 * (q_);                                                      \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                         \
-                f32x4 v = y[r] + bias[i];                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+                f32x4 v = y[i] + bias;                                                              \
                 if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);                            \
-                if (col_ok[i] && oy + r < p.Ho && ox < p.Wo)                                        \
-                    *reinterpret_cast<f32x4 *>(obase[i] + (size_t)((4 * (q_) + r) * p.Wo) * p.out_pix_stride) = v; \
+                if (col_ok && oy + i < p.Ho && ox < p.Wo)                                           \
+                    *reinterpret_cast<f32x4 *>(obase + (size_t)((4 * (q_) + i) * p.Wo) * p.out_pix_stride) = v; \
             }                                                                                       \
         }                                                                                           \
         W4S_LDS_BARRIER();                                                                          \
     } while (0)
         // the stream load the last chunk skipped is issued after the first dump; the first B operands of the block's next tile
         // are fetched under the last pass (without a next tile the loads re-read this tile's and are dropped)
-        W4S_PASS(0, W4S_LOAD_STREAM(0););
+        W4S_PASS(0, W4S_LOAD_STREAM(););
         W4S_PASS(1, );
         W4S_PASS(2, );
         W4S_PASS(3,
                  w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                      const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)nxt_nb * nchunks * UC_BYTES), 0, 0x7fffffff, 0x00020000);
-                 W4S_LOAD_U(0, 0, 0); W4S_LOAD_U(1, 0, 1););
+                 W4S_PRELOAD_U(););
 #undef W4S_PASS
 #undef W4S_LDS_BARRIER
 
@@ -550,7 +545,7 @@ hipError_t launch_conv3x3_wino4s(const ConvLaunch &p, int nb0, int nblk, hipStre
     const int total = tiles * p.nimg * nblk;
     const int pcap = p.w4_persist > 1 ? p.w4_persist : n_cu;
     const int pgrid = pcap < total ? pcap : total;
-    hipLaunchKernelGGL(conv3x3_wino4s, dim3((unsigned)pgrid), dim3(256), LDS_BYTES, s, q);
+    hipLaunchKernelGGL(conv3x3_wino4s, dim3((unsigned)pgrid), dim3(512), LDS_BYTES, s, q);
     return hipGetLastError();
 }
 

@@ -100,6 +100,35 @@ def test_conv3x3_wino4_persistent_blocks(hard, ci, co, h, w, blocks):
     assert np.array_equal(got, one_tile)
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+@pytest.mark.parametrize("ci,co,h,w,blocks", [(128, 128, 40, 70, 3), (200, 128, 33, 65, 5), (32, 64, 17, 100, 2), (104, 192, 48, 33, 7),
+                                              (64, 100, 70, 31, 64), (96, 160, 16, 32, 2)])
+def test_conv3x3_wino4_split_operands(hard, scale, ci, co, h, w, blocks):
+    """Option wino4_split = 1: the F(4x4) GEMMs on the bf16 matrix pipe with every fp32 operand split exactly into three bf16
+    terms, six of the nine term products kept (b2f_wino4s.hip).  The claim is fp32-level accuracy: against an fp64 convolution
+    its error must stay inside the fp32-MFMA kernel's own bars (the same atol / mean bars as test_conv3x3, in proportion to
+    the activation scale) and within 1.25x of the fp32 kernel's measured error on the same case; and the bits must not depend
+    on how many persistent blocks walk the tiles."""
+    import torch
+    r = _rng(ci * 11 + co + blocks)
+    x = (r.standard_normal((3, ci, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = (r.standard_normal(co, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
+    exp = torch.where(y > 0, y, 0.2 * y).numpy()
+    with hard.options(wino4_persistent=blocks, wino4_split=0):
+        f32 = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino4_persistent=blocks, wino4_split=1):
+        got = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino4_persistent=1, wino4_split=1):
+        got1 = ops.conv3x3(hard, x, wt, b, 1, True)
+    assert not np.array_equal(got, f32)                      # the other kernel really ran
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert es.max() <= 1.5e-4 * scale and es.mean() < 5e-6 * scale
+    assert es.mean() <= 1.25 * ef.mean() and es.max() <= 1.25 * ef.max() + 1e-5 * scale
+    assert np.array_equal(got, got1)
+
+
 @pytest.mark.parametrize("scale", [1e-3, 30.0, 1e3])
 @pytest.mark.parametrize("ci,co,h,w", [(128, 128, 33, 65), (200, 96, 40, 70)])
 def test_conv3x3_wino4_activation_scale(hard, scale, ci, co, h, w):
@@ -316,6 +345,26 @@ def test_compute_flow_either_winograd_kernel(hard, min_px, adaptive):
     eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
     d = np.abs(flow - eflow)
     assert np.abs(eflow).max() > 0.02 and d.max() <= 1e-3, d.max()
+    near = np.abs(onet - 0.6666) < 1e-3
+    assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
+
+
+def test_compute_flow_with_split_operand_winograd(hard):
+    """The whole graph with every two-N-tile F(4x4) launch on the bf16 matrix pipe (option wino4_split, split fp32 operands):
+    same end-to-end bar as the default path; the option repacks the weights when it is switched and back."""
+    r = _rng(14)
+    H, Wd = 128, 256
+    ims = _triplet(r, H, Wd)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
+    with hard.options(wino4_min_pixels=0, host_graph=0):
+        base, _, _ = hard.computeFlow(*ims)
+        with hard.options(wino4_split=1):
+            flow, fo, bo = hard.computeFlow(*ims)
+        again, _, _ = hard.computeFlow(*ims)
+    d = np.abs(flow - eflow)
+    assert np.abs(eflow).max() > 0.02 and d.max() <= 1e-3, d.max()
+    assert not np.array_equal(flow, base) and np.abs(flow - base).max() < 1e-5     # another kernel, the same function
+    assert np.array_equal(again, base)
     near = np.abs(onet - 0.6666) < 1e-3
     assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
 
