@@ -45,10 +45,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace wino4 {
 constexpr int TH = 16, TW = 32;             // output pixels per block
 constexpr int PH = TH + 2, PW = TW + 2;     // 18 x 34 input patch
-constexpr int RW = 38;                      // float4 per patch row in LDS; RW = 2 (mod 4) puts the two tile rows of a
-                                            // 16-lane ds_read_b128 group 128 B apart in bank space
-constexpr int RAW_P = PH * RW;              // 684 float4 per k4 plane
-constexpr int RAW_F4 = 2 * RAW_P;           // per raw buffer
+// LDS layouts (round 4): both the raw patch and V are stored as planes of channel PAIRS (f32x2), so that the 8-byte accesses
+// of the input transform (a thread handles one channel pair) are bank-conflict free: a 32-lane group of a ds_read_b64 /
+// ds_write_b64 covers 256 contiguous bytes.  Measured before (SQ_LDS_BANK_CONFLICT per ablation build, tools/w4_lds_conflicts.sh):
+// 35 % of the kernel's LDS cycles were conflicts -- 49 % of them the transform's reads of the float4-per-pixel patch (tile rows
+// t and t + 2 of a 32-lane group on the same banks), 36 % its writes of float4-per-tile V (tiles t and t + 16), 9 % the staging
+// writes, 6 % the output stage, none the A operand reads or the accumulator dump (profiles/r04_wino4_notes.txt).
+//   raw  [2 buf][k4 2][pair 2][18 rows][RWP] f32x2, columns permuted colpos(p); RWP = 2 (mod 8) puts the four tile rows of a
+//        32-lane group 64 B apart in bank space
+//   V    [2 buf][36 xi][k4 2][pair 2][32 tiles] f32x2; the A operand (4 channels of a tile) is one ds_read2_b64
+constexpr int RWP = 42;                     // f32x2 per patch row of a pair plane
+constexpr int PL2 = PH * RWP;               // 756 f32x2 per (k4, pair) plane
+constexpr int RAW_F4 = 2 * PL2;             // float4 per raw buffer (4 planes)
 constexpr int V_F4 = 36 * 2 * 32;           // per V buffer
 constexpr int NITEM = 2 * PH * PW;          // 1224 (pixel, k4) staging items per chunk
 constexpr int U_F4 = 36 * 2 * 64;           // float4 of packed weights per (n-block, chunk)
@@ -61,6 +69,15 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 }  // namespace wino4
 
 #define W4_FMA(a_, b_, c_) __builtin_elementwise_fma((a_), (b_), (c_))
+// float4 (4 channels of a pixel's k4 group) -> the two pair planes of a raw buffer; slot2_ = f32x2 index in pair plane 0
+#define W4_RAW_STORE(buf4_, slot2_, v_)                                                             \
+    do {                                                                                            \
+        f32x2 *r2__ = reinterpret_cast<f32x2 *>(buf4_) + (slot2_);                                  \
+        r2__[0] = __builtin_shufflevector((v_), (v_), 0, 1);                                        \
+        r2__[wino4::PL2] = __builtin_shufflevector((v_), (v_), 2, 3);                               \
+    } while (0)
+// A operand: the 4 channels (two pair planes) of V[xi][k4][tile] as one ds_read2_b64; p2_ = f32x2 pointer at pair 0
+#define W4_A_READ(p2_) __builtin_shufflevector((p2_)[0], (p2_)[32], 0, 1, 2, 3)
 
 // Profiling only: -DB2F_WINO_TRACE=1 records clock64() at five points of every main-loop iteration of a
 // few blocks (p.trace, set by the launcher when B2F_WINO_TRACE is in the environment).
@@ -68,7 +85,8 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 #define B2F_WINO_TRACE 0
 #endif
 // Profiling only (results are wrong): -DB2F_WINO4_ABLATE=bits, 1 no input transform, 2 no raw staging, 4 no B loads,
-// 8 no MFMAs, 16 no A operand reads
+// 8 no MFMAs, 16 no A operand reads; persistent two-N-tile kernel only: 64 no accumulator dump, 128 no output transform (LDS reads + stores),
+// 256 transform without its LDS reads, 512 transform without its LDS writes
 #ifndef B2F_WINO4_ABLATE
 #define B2F_WINO4_ABLATE 0
 #endif
@@ -228,8 +246,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         s_ok[i] = in_patch && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         const unsigned gp = s_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;
         s_off[i] = (gp * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
-        s_slot[i] = (tid & 1) * RAW_P + (in_patch ? py * RW + colpos(px) : 0);
-        if (in_patch && !s_ok[i]) { Rb[s_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; Rb[RAW_F4 + s_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        s_slot[i] = (tid & 1) * 2 * PL2 + (in_patch ? py * RWP + colpos(px) : 0);    // f32x2 index of pair 0; pair 1 -> + PL2
+        if (in_patch && !s_ok[i]) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            W4_RAW_STORE(Rb, s_slot[i], z4);
+            W4_RAW_STORE(Rb + RAW_F4, s_slot[i], z4);
+        }
     }
 
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
@@ -255,7 +277,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 #define W4_WRITE_RAW(buf_)                                                                          \
     do {                                                                                            \
         f32x4 *r = Rb + (buf_) * RAW_F4;                                                            \
-        _Pragma("unroll") for (int i = 0; i < 3; ++i) if (s_ok[i]) r[s_slot[i]] = sr[i];            \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) if (s_ok[i]) W4_RAW_STORE(r, s_slot[i], sr[i]); \
     } while (0)
 
 #define W4_MAYBE_CONST const
@@ -283,18 +305,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     }
     const bool t_two = t_role < 2;                               // two output rows (t_orow, t_orow + 1)
     const int t_tile = lane & 31, t_k4 = lane >> 5;
-    const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
-    W4_MAYBE_CONST int t_row[4] = {t_base + rx1 * RW, t_base + rx2 * RW, t_base + rx3 * RW, t_base + rx4 * RW};
-    W4_MAYBE_CONST int t_dst = (t_orow * 6 * 2 + t_k4) * 32 + t_tile;   // float4 index of V[xi = 6 t_orow][k4][t]; xi+1 -> +64, next row -> +384
+    const int t_base = (t_k4 * 2 + th) * PL2 + (4 * (t_tile >> 3)) * RWP + (t_tile & 7);   // f32x2 index in this thread's pair plane
+    W4_MAYBE_CONST int t_row[4] = {t_base + rx1 * RWP, t_base + rx2 * RWP, t_base + rx3 * RWP, t_base + rx4 * RWP};
+    W4_MAYBE_CONST int t_dst = ((t_orow * 6 * 2 + t_k4) * 2 + th) * 32 + t_tile;   // f32x2 index of V[xi = 6 t_orow][k4][pair th][t]; xi+1 -> +128, next row -> +768
     f32x4 R[6], d[NTV == 1 ? 4 : 2];   // R[j] = (row A of column j | row B); d = (x1 | x2), (x3 | x4) of a column
     // slice s < 6: column s of the 6-wide tile window (reads of its four rows, then the four packed ops); slice 6 / 7: column
     // pass + LDS writes of the first / second produced row into V buffer vbuf_
 #define W4_T_READ(s_, rbuf_) W4_T_READ_D(s_, rbuf_, 0)
 #define W4_T_READ_D(s_, rbuf_, db_)                                                                 \
     do {                                                                                            \
-        if ((s_) < 6) {                                                                             \
-            const f32x2 *rp = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4 + colpos(s_)) + th; \
-            const f32x2 x1 = rp[2 * t_row[0]], x2 = rp[2 * t_row[1]], x3 = rp[2 * t_row[2]], x4 = rp[2 * t_row[3]]; \
+        if ((s_) < 6 && !(B2F_WINO4_ABLATE & 256)) {                                                \
+            const f32x2 *rp = reinterpret_cast<const f32x2 *>(Rb + (rbuf_) * RAW_F4) + colpos(s_);  \
+            const f32x2 x1 = rp[t_row[0]], x2 = rp[t_row[1]], x3 = rp[t_row[2]], x4 = rp[t_row[3]]; \
             d[(db_)] = __builtin_shufflevector(x1, x2, 0, 1, 2, 3);                                 \
             d[(db_) + 1] = __builtin_shufflevector(x3, x4, 0, 1, 2, 3);                             \
         }                                                                                           \
@@ -344,8 +366,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o2) : "v"(pq), "v"(qq)); \
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o3) : "s"(k2v), "v"(vv), "v"(uu));        \
         asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o4) : "s"(km2), "v"(vv), "v"(uu));        \
-        f32x2 *v = reinterpret_cast<f32x2 *>(Vb + (vbuf_) * VSTRIDE + t_dst + 384 * (hh_)) + th;    \
-        v[0] = t0; v[2 * 64] = o1; v[2 * 128] = o2; v[2 * 192] = o3; v[2 * 256] = o4; v[2 * 320] = t1; \
+        f32x2 *v = reinterpret_cast<f32x2 *>(Vb + (vbuf_) * VSTRIDE) + t_dst + 768 * (hh_);         \
+        if (!(B2F_WINO4_ABLATE & 512)) { v[0] = t0; v[128] = o1; v[2 * 128] = o2; v[3 * 128] = o3; v[4 * 128] = o4; v[5 * 128] = t1; } \
+        else asm volatile("" :: "v"(t0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(t1));              \
     } while (0)
 #define W4_T_COLS(vbuf_) do {} while (0)      /* (the column passes are slices 6, 7 of W4_T_FMA now) */
 
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
     const bool mf_on = n < NTV;                                          // this wave's N tile holds real channels
-    const int a_off = (9 * g * 2 + half) * 32 + m;                       // V[xi = 9g][k4 = half][tile m]; xi+1 -> +64
+    const int a_off = (9 * g * 2 + half) * 2 * 32 + m;                   // f32x2 index of V[xi = 9g][k4 = half][pair 0][tile m]; pair 1 -> +32, xi+1 -> +128
     const unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u; // bytes: U[xi = 9g][k4 = half][co]; xi+1 -> +2048
     f32x4 av[3], bv[6];
     // buffer loads: 128-bit resource (scalar), one 32-bit lane offset, scalar (chunk, xi) offset -- no per-load
@@ -395,8 +418,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     W4_T_READ(1, 1); W4_T_FMA(1, 0);
     W4_T_READ(2, 1);
     __syncthreads();
-    av[0] = Vb[a_off];
-    av[1] = Vb[a_off + 64];
+    av[0] = W4_A_READ(reinterpret_cast<const f32x2 *>(Vb) + a_off);
+    av[1] = W4_A_READ(reinterpret_cast<const f32x2 *>(Vb) + a_off + 128);
 
 #if B2F_WINO_TRACE
     const int tr_slot = blockIdx.x == 300 ? 0 : blockIdx.x == 301 ? 1 : blockIdx.x == 1200 ? 2 : blockIdx.x == 1456 ? 3 : -1;
@@ -416,8 +439,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         const int c = (c_);                                                                         \
         W4_T(0);                                                                                    \
         const int cn = min(c + 1, nchunks - 1);                                                     \
-        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;                                              \
-        const f32x4 *Vn = Vb + ((c + 1) & 1) * V_F4 + a_off;                                        \
+        const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + (c & 1) * V_F4) + a_off;             \
+        const f32x2 *Vn = reinterpret_cast<const f32x2 *>(Vb + ((c + 1) & 1) * V_F4) + a_off;       \
         _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
             /* B operand five xi ahead (next chunk's for x >= 4); A operand one xi ahead (xi 8 two ahead, so */ \
             /* that every read of V[c & 1] is issued before the barrier; xi 0, 1 of the next chunk after it) */ \
@@ -426,10 +449,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
                 else W4_LOAD_U((9 * (PH_) + x + 5) % 6, cn, x + 5 - 9);                             \
             }                                                                                       \
             if (!(B2F_WINO4_ABLATE & 16)) {                                                         \
-                if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                           \
-                if (x == 6) av[8 % 3] = Vc[8 * 64];                                                 \
-                if (x == 7) av[0] = Vn[0];                                                          \
-                if (x == 8) av[1] = Vn[64];                                                         \
+                if (x >= 1 && x <= 6) av[(x + 1) % 3] = W4_A_READ(Vc + (x + 1) * 128);              \
+                if (x == 6) av[8 % 3] = W4_A_READ(Vc + 8 * 128);                                    \
+                if (x == 7) av[0] = W4_A_READ(Vn);                                                  \
+                if (x == 8) av[1] = W4_A_READ(Vn + 128);                                            \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (!(B2F_WINO4_ABLATE & 8) && (NTV == 2 || mf_on)) {                                   \
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
     int xo[5];
 #pragma unroll
     for (int x = 0; x < 5; ++x) xo[x] = min(9 * g + 5 * n + x, 35);
-    const int a_lane = half * 32 + m;                       // V[xi][k4 = half][tile m] = xi * 64 + a_lane (float4)
+    const int a_lane = half * 2 * 32 + m;                   // f32x2 index: V[xi][k4 = half][pair 0][tile m] = xi * 128 + a_lane; pair 1 -> + 32
     const unsigned b_lane = (half * 64 + m) * 16u;          // bytes: U[xi][k4 = half][co m] = xi * 2048 + b_lane
     f32x4 av[5], bc[5], bn[5];
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
@@ -582,9 +605,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
         const int cn = min(c + 1, nchunks - 1);
         W4S_LOAD_U(bn, cn);
         W4_LOAD_RAW(min(c + 2, nchunks - 1));
-        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_lane;
+        const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + (c & 1) * V_F4) + a_lane;
 #pragma unroll
-        for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
+        for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);
 #pragma unroll
         for (int x = 0; x < 5; ++x) {
             if (x < 4) { W4_T_READ_D(2 * x, (c + 1) & 1, 0); W4_T_READ_D(2 * x + 1, (c + 1) & 1, 2); }
@@ -673,7 +696,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     {
         const int pix = min(tid, NSTG - 1) >> 1;
         const int r6 = pix / PW, px = pix - r6 * PW;
-        s_slot = (tid & 1) * RAW_P + r6 * RW + colpos(px);
+        s_slot = (tid & 1) * 2 * PL2 + r6 * RWP + colpos(px);     // f32x2 index of pair 0; pair 1 -> + PL2
         l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
     }
     const int rowblk = 6 * p.W * p.seg[0].pix_stride * 4;        // bytes between the items of a thread
@@ -741,8 +764,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     } while (0)
 #define W4P_WRITE_RAW(buf_)                                                                         \
     do {                                                                                            \
-        f32x4 *r = Rb + (buf_) * RAW_F4 + s_slot;                                                   \
-        if (s_act) { r[0] = sr[0]; r[6 * RW] = sr[1]; r[12 * RW] = sr[2]; }                         \
+        f32x4 *r = Rb + (buf_) * RAW_F4;                                                            \
+        if (s_act) { W4_RAW_STORE(r, s_slot, sr[0]); W4_RAW_STORE(r, s_slot + 6 * RWP, sr[1]); W4_RAW_STORE(r, s_slot + 12 * RWP, sr[2]); } \
     } while (0)
 
     // ---- input transform role (as in conv3x3_wino4: row pairs with shared sub-expressions, channel pair th = wave & 1) ----
@@ -758,14 +781,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     }
     const bool t_two = t_role < 2;
     const int t_tile = lane & 31, t_k4 = lane >> 5;
-    const int t_base = t_k4 * RAW_P + (4 * (t_tile >> 3)) * RW + (t_tile & 7);
-    int t_row[4] = {t_base + rx1 * RW, t_base + rx2 * RW, t_base + rx3 * RW, t_base + rx4 * RW};
-    int t_dst = (t_orow * 6 * 2 + t_k4) * 32 + t_tile;
+    const int t_base = (t_k4 * 2 + th) * PL2 + (4 * (t_tile >> 3)) * RWP + (t_tile & 7);
+    int t_row[4] = {t_base + rx1 * RWP, t_base + rx2 * RWP, t_base + rx3 * RWP, t_base + rx4 * RWP};
+    int t_dst = ((t_orow * 6 * 2 + t_k4) * 2 + th) * 32 + t_tile;
     f32x4 R[6], d[NTV == 1 ? 4 : 2];
 
     if constexpr (NTV == 2) {
     f32x16 acc[9];
-    int a_off = (9 * g * 2 + half) * 32 + m;
+    int a_off = (9 * g * 2 + half) * 2 * 32 + m;
     unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
     f32x4 av[3], bv[6];
     __amdgpu_buffer_rsrc_t w_rsrc;
@@ -798,8 +821,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         for (int i = 0; i < 3; ++i) keep[i] = sr[i];
         W4P_LOAD_STREAM();                       // chunk 1
         if (s_act) {
-            f32x4 *r = Rb + s_slot;
-            r[0] = keep[0]; r[6 * RW] = keep[1]; r[12 * RW] = keep[2];
+            W4_RAW_STORE(Rb, s_slot, keep[0]); W4_RAW_STORE(Rb, s_slot + 6 * RWP, keep[1]); W4_RAW_STORE(Rb, s_slot + 12 * RWP, keep[2]);
         }
         W4P_WRITE_RAW(1);
         W4P_LOAD_STREAM();                       // chunk 2, stays in flight
@@ -833,21 +855,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             asm volatile("" : "+v"(lz));
             const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)lz));
             const int lm = ln & 31, lh = ln >> 5, ltid = wave * 64 + ln;
-            const int tb = lh * RAW_P + (4 * (lm >> 3)) * RW + (lm & 7);
-            t_row[0] = tb + rx1 * RW; t_row[1] = tb + rx2 * RW; t_row[2] = tb + rx3 * RW; t_row[3] = tb + rx4 * RW;
-            t_dst = (t_orow * 6 * 2 + lh) * 32 + lm;
-            a_off = (9 * g * 2 + lh) * 32 + lm;
+            const int tb = (lh * 2 + th) * PL2 + (4 * (lm >> 3)) * RWP + (lm & 7);
+            t_row[0] = tb + rx1 * RWP; t_row[1] = tb + rx2 * RWP; t_row[2] = tb + rx3 * RWP; t_row[3] = tb + rx4 * RWP;
+            t_dst = ((t_orow * 6 * 2 + lh) * 2 + th) * 32 + lm;
+            a_off = (9 * g * 2 + lh) * 2 * 32 + lm;
             b_off = ((9 * g * 2 + lh) * 64 + n * 32 + lm) * 16u;
             const int pix = min(ltid, NSTG - 1) >> 1;
             const int r6 = pix / PW, px = pix - r6 * PW;
-            s_slot = (ltid & 1) * RAW_P + r6 * RW + colpos(px);
+            s_slot = (ltid & 1) * 2 * PL2 + r6 * RWP + colpos(px);
             l_off = ((unsigned)(r6 * p.W + px) * (unsigned)p.seg[0].pix_stride + (ltid & 1) * 4) * 4u;
         }
         W4_T_READ(0, par ^ 1); W4_T_FMA(0, 0);
         W4_T_READ(1, par ^ 1); W4_T_FMA(1, 0);
         W4_T_READ(2, par ^ 1);
-        av[0] = Vb[par * VSTRIDE + a_off];
-        av[1] = Vb[par * VSTRIDE + a_off + 64];
+        av[0] = W4_A_READ(reinterpret_cast<const f32x2 *>(Vb + par * VSTRIDE) + a_off);
+        av[1] = W4_A_READ(reinterpret_cast<const f32x2 *>(Vb + par * VSTRIDE) + a_off + 128);
 #pragma unroll
         for (int x = 0; x < 9; ++x)
 #pragma unroll
@@ -857,24 +879,28 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     do {                                                                                            \
         const int c = (c_);                                                                         \
         const int pc = (par + c) & 1;                                                               \
-        const f32x4 *Vc = Vb + pc * VSTRIDE + a_off;                                                \
-        const f32x4 *Vn = Vb + (pc ^ 1) * VSTRIDE + a_off;                                          \
+        const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_off;               \
+        const f32x2 *Vn = reinterpret_cast<const f32x2 *>(Vb + (pc ^ 1) * VSTRIDE) + a_off;         \
         _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
             if (x + 5 < 9) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c, x + 5);                           \
             else if (!(LAST_)) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c + 1, x + 5 - 9);               \
-            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                               \
-            if (x == 6) av[8 % 3] = Vc[8 * 64];                                                     \
-            if (x == 7) av[0] = Vn[0];                                                              \
-            if (x == 8) av[1] = Vn[64];                                                             \
+            if (!(B2F_WINO4_ABLATE & 16)) {                                                         \
+                if (x >= 1 && x <= 6) av[(x + 1) % 3] = W4_A_READ(Vc + (x + 1) * 128);              \
+                if (x == 6) av[8 % 3] = W4_A_READ(Vc + 8 * 128);                                    \
+                if (x == 7) av[0] = W4_A_READ(Vn);                                                  \
+                if (x == 8) av[1] = W4_A_READ(Vn + 128);                                            \
+            }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
                 acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[(9 * (PH_) + x) % 6][j], acc[x], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            if (x < 6) {                                                                            \
+            if (B2F_WINO4_ABLATE & 1) {                                                             \
+                if (x == 6) { if (!(B2F_WINO4_ABLATE & 2)) W4P_WRITE_RAW(pc); __builtin_amdgcn_sched_barrier(0); __syncthreads(); if (!(LAST_)) W4P_LOAD_STREAM(); } \
+            } else if (x < 6) {                                                                     \
                 W4_T_FMA(x + 2, pc ^ 1);                                                            \
                 if (x + 3 < 8) W4_T_READ(x + 3, pc ^ 1);                                            \
             } else if (x == 6) {                                                                    \
-                W4P_WRITE_RAW(pc);                                                                  \
+                if (!(B2F_WINO4_ABLATE & 2)) W4P_WRITE_RAW(pc);                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 __syncthreads();                                                                    \
                 W4_T_READ(0, pc);                                                                   \
@@ -949,6 +975,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #define W4P_PASS(q_, EXTRA_)                                                                              \
     do {                                                                                            \
         asm volatile("; dump of tile row %0" ::"n"(q_));                                            \
+        if (!(B2F_WINO4_ABLATE & 64))                                                               \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
             const unsigned da = xbase + dump_rel[e];                                                \
             _Pragma("unroll") for (int x = 0; x < 8; x += 2)                                        \
@@ -960,7 +987,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         W4P_LDS_BARRIER();                                                                          \
         W4P_T(4 + 3 * (q_));                                                                        \
         EXTRA_                                                                                      \
-        {                                                                                           \
+        if (!(B2F_WINO4_ABLATE & 128)) {                                                            \
             const f32x4 sg4 = {o_sg, o_sg, o_sg, o_sg}, kq4 = {o_kq, o_kq, o_kq, o_kq};             \
             const f32x4 k04 = {o_k0, o_k0, o_k0, o_k0}, k34 = {o_k3, o_k3, o_k3, o_k3};             \
             const f32x4 k2 = {2.f, 2.f, 2.f, 2.f}, k4 = {4.f, 4.f, 4.f, 4.f}, k8 = {8.f, 8.f, 8.f, 8.f}; \
@@ -1028,7 +1055,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     int xo[5];
 #pragma unroll
     for (int x = 0; x < 5; ++x) xo[x] = min(9 * g + 5 * n + x, 35);
-    const int a_lane = half * 32 + m;                       // V[xi][k4 = half][tile m] = xi * 64 + a_lane (float4)
+    const int a_lane = half * 2 * 32 + m;                   // f32x2 index: V[xi][k4 = half][pair 0][tile m] = xi * 128 + a_lane; pair 1 -> + 32
     const unsigned b_lane = (half * 64 + m) * 16u;          // bytes: U[xi][k4 = half][co m] = xi * 2048 + b_lane
     f32x4 av[5], bc[5], bn[5];
     if ((int)blockIdx.x >= total) return;
@@ -1053,8 +1080,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         W4P_LOAD_STREAM();                       // chunk 1
         W4Q_LOAD_U(bc, 0);
         if (s_act) {
-            f32x4 *r = Rb + s_slot;
-            r[0] = keep[0]; r[6 * RW] = keep[1]; r[12 * RW] = keep[2];
+            W4_RAW_STORE(Rb, s_slot, keep[0]); W4_RAW_STORE(Rb, s_slot + 6 * RWP, keep[1]); W4_RAW_STORE(Rb, s_slot + 12 * RWP, keep[2]);
         }
         W4P_WRITE_RAW(1);
     }
@@ -1077,9 +1103,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             const int cn = c + 1 < nchunks ? c + 1 : 0;          // after the last chunk: chunk 0 of the next tile (same weights)
             W4Q_LOAD_U(bn, cn);
             W4P_LOAD_STREAM();                                   // two chunks ahead (runs on into the next tile)
-            const f32x4 *Vc = Vb + pc * VSTRIDE + a_lane;
+            const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_lane;
 #pragma unroll
-            for (int x = 0; x < 5; ++x) av[x] = Vc[xo[x] * 64];
+            for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);
 #pragma unroll
             for (int x = 0; x < 5; ++x) {
                 if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 2); }
