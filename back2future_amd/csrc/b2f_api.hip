@@ -184,7 +184,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             total += wino_wpk_floats(chunks, p.nt2, p.nblk2);
             p.b_off2 = total;
             total += (size_t)p.nblk2 * p.nt2 * 32;
-            if (c->wino4_split) {                    // only while the option is on: 1.5x the F(4x4) packing
+            if (c->wino4_split || c->wino4_hybrid) { // only while an option that reads it is on: 1.5x the F(4x4) packing
                 total = (total + 3) & ~(size_t)3;    // 16-byte aligned: the split weights are read with dwordx4 loads
                 p.w_off3 = total;
                 total += wino4s_wpk_floats(chunks, p.nblk);
@@ -375,7 +375,8 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.leaky = leaky;
     L.tiles_per_block = c->s2_tiles_per_block;
     L.w4_persist = c->wino4_persistent;
-    L.wpk_split = (mode == 4 && c->wino4_split && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
+    L.wpk_split = (mode == 4 && (c->wino4_split || c->wino4_hybrid) && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
+    L.w4_hybrid = c->wino4_hybrid;
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
@@ -748,6 +749,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
+        c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
         c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
         c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
@@ -857,13 +859,13 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
-    else if (!strcmp(key, "wino4_split")) {
+    else if (!strcmp(key, "wino4_split") || !strcmp(key, "wino4_hybrid")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
-        const bool repack = (value != 0) != (c->wino4_split != 0);
-        c->wino4_split = value;
-        if (repack) CHK(b2f_commit_weights(c));   // the split packing exists only while the option is on
+        const bool had = c->wino4_split || c->wino4_hybrid;
+        (key[6] == 's' ? c->wino4_split : c->wino4_hybrid) = value;
+        if (had != (c->wino4_split || c->wino4_hybrid)) CHK(b2f_commit_weights(c));   // the split packing exists only while an option reads it
     }
     else if (!strcmp(key, "s2_tiles_per_block") || !strcmp(key, "wino4_persistent")) {
         HIPCHK(hipSetDevice(c->device));
@@ -910,6 +912,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "wino4_split") *value = c->wino4_split;
+    else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
@@ -1288,7 +1291,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     DevBuf dpl, dx, dw, db, dy, dyp, dws;
     const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
     CHK(dpl.alloc(nx)); CHK(dx.alloc(nxp)); CHK(dw.alloc(wpk.size())); CHK(db.alloc(bpk.size())); CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
-    if (wino == 4 && c->wino4_split) {
+    if (wino == 4 && (c->wino4_split || c->wino4_hybrid)) {
         std::vector<float> wps(wino4s_wpk_floats(chunks, nblk));
         wino4s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
         CHK(dws.alloc(wps.size()));
@@ -1310,6 +1313,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.nb0 = 0; L.trace = nullptr;
     L.w4_persist = c->wino4_persistent;
     L.wpk_split = dws.p;
+    L.w4_hybrid = c->wino4_hybrid;
     if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

@@ -228,6 +228,8 @@ struct b2f_ctx {
     int corr_variant = -1;         // warp + cost volume: -1 auto, 0 regular, 1 latency variant (bit-identical results)
     int op_wino_split = 0;         // b2f_op_conv3x3: F(2x2) kernel with one block per 32-output N tile (tests)
     int profile_layers = 0;        // one profile row per (layer shape, map size)
+    int wino4_hybrid = 0;          // F(4x4) two-N-tile blocks: this many of a wave's nine xi steps on the bf16 pipe with split operands (needs the
+                                   // split packing: setting it > 0 packs it); 0 = all on the fp32 MFMA
     int wino4_split = 0;           // F(4x4) layers with two full N tiles per block: 1 = on the bf16 matrix pipe with exactly split fp32 operands
                                    // (b2f_wino4s.hip; fp32-level accuracy, measured no faster: profiles/r04_wino4s_notes.txt), 0 = on the fp32 MFMA
     int wino4_persistent = 1;      // F(4x4) kernel: 1 = persistent blocks (one per CU, K pipeline continues across tiles), 0 = one tile per block, > 1 = that many persistent blocks (tests)

@@ -55,6 +55,7 @@ struct ConvLaunch {
     int nsplit;         // F(2x2) kernel: 1 = one block per 32-output N tile of the 64-wide packing (more, lighter blocks for small launches)
     int w4_persist = 1;        // F(4x4) kernel: persistent blocks (one per CU) when the launch has at least two tiles per CU
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
+    int w4_hybrid = 0;                 // F(4x4) persistent two-N-tile kernel: xi steps per wave that run on the bf16 pipe with split operands (0 = none)
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);

@@ -41,6 +41,34 @@ namespace b2f {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- hybrid steps (round 4): some of a wave's nine xi steps run on the BF16 matrix pipe with exactly split fp32 operands
+// (b2f_wino4s.hip explains the split: x = xh + xm + xl, six of nine term products, fp32-level accuracy) instead of four fp32
+// MFMAs.  A fp32 MFMA blocks the SIMD's matrix pipe AND its VALU for 64 cycles (tools/mfma_bf16_chain.hip mode 18: fp32 and
+// bf16 MFMAs of two waves add up; r01: fp32 MFMA and VALU add up); three bf16 MFMAs hold the matrix pipe for 96 cycles and leave
+// the VALU to the other wave, at the price of ~26 VALU instructions for the split.
+__device__ __forceinline__ unsigned w4h_pk(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// fp32 quad -> window [m01 m23 | h01 h23 | l01 l23] of bf16 pairs (round to nearest even; x = h + m + l exactly)
+__device__ __forceinline__ void w4h_split(const f32x4 v, unsigned (&w)[6])
+{
+    const unsigned h01 = w4h_pk(v[0], v[1]), h23 = w4h_pk(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16), r1 = v[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16), r3 = v[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
+    const unsigned m01 = w4h_pk(r0, r1), m23 = w4h_pk(r2, r3);
+    const float l0 = r0 - __builtin_bit_cast(float, m01 << 16), l1 = r1 - __builtin_bit_cast(float, m01 & 0xffff0000u);
+    const float l2 = r2 - __builtin_bit_cast(float, m23 << 16), l3 = r3 - __builtin_bit_cast(float, m23 & 0xffff0000u);
+    w[0] = m01; w[1] = m23; w[2] = h01; w[3] = h23;
+    w[4] = w4h_pk(l0, l1);
+    w[5] = w4h_pk(l2, l3);
+}
 
 namespace wino4 {
 constexpr int TH = 16, TW = 32;             // output pixels per block
@@ -64,7 +92,9 @@ constexpr int STAGE_BYTES = 16 * (2 * V_F4 + 2 * RAW_F4);
 constexpr int XCH_BYTES = 36 * 32 * 32 * 4;
 constexpr int LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
 constexpr int XQ_F4 = 36 * 8 * 64 / 4;                   // persistent kernel: exchange buffer of one tile row (8 tiles x 64 co x 36 xi)
-constexpr int P_LDS_BYTES = 16 * (2 * RAW_F4 + XQ_F4 + V_F4);   // [raw 0 | raw 1 | V 0 | gap | V 1] = 154 368
+constexpr int P_LDS_BYTES = 16 * (2 * RAW_F4 + XQ_F4 + V_F4);   // [raw 0 | raw 1 | V 0 | gap | V 1] = 158 976
+constexpr int US4_BYTES = 36 * 2 * 64 * 16;  // split weights of one (n-block, chunk): (Um Um Uh Uh) plane, then the (Ul Ul) plane (b2f_wino4s.hip)
+constexpr int USC_BYTES = US4_BYTES + 36 * 2 * 64 * 8;
 __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2); }
 }  // namespace wino4
 
@@ -663,7 +693,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4(const ConvLaunch p)
 // Zero padding comes from the buffer loads' range check (offset >= num_records reads 0), so the staging state of
 // a tile is three byte offsets per thread and no LDS slot is ever "pre-zeroed".
 // =========================================================================================================
-template <int NTV>
+// HYB: bit x set = xi step x of every wave runs on the bf16 pipe with split operands (NTV == 2 only; needs p.wpk_split)
+template <int NTV, int HYB = 0>
 __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 {
     using namespace wino4;
@@ -791,9 +822,46 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     int a_off = (9 * g * 2 + half) * 2 * 32 + m;
     unsigned b_off = ((9 * g * 2 + half) * 64 + n * 32 + m) * 16u;
     f32x4 av[3], bv[6];
-    __amdgpu_buffer_rsrc_t w_rsrc;
+    __amdgpu_buffer_rsrc_t w_rsrc, ws_rsrc;
+    u32x2 bl[6];                                                  // third term of the split B operand (hybrid steps only)
+#define W4P_HYB(x_) ((HYB >> (x_)) & 1)
 #define W4P_LOAD_U(slot_, c_, x_)                                                                   \
-    bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((c_) * (U_F4 * 16) + (x_) * 2048), 0))
+    do {                                                                                            \
+        if (W4P_HYB(x_)) {                                                                          \
+            bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc, (int)b_off, (int)((c_) * USC_BYTES + (x_) * 2048), 0)); \
+            bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ws_rsrc, (int)(b_off >> 1), (int)((c_) * USC_BYTES + US4_BYTES + (x_) * 1024), 0)); \
+        } else {                                                                                    \
+            bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((c_) * (U_F4 * 16) + (x_) * 2048), 0)); \
+        }                                                                                           \
+    } while (0)
+#define W4P_RSRC_U(nb_)                                                                             \
+    do {                                                                                            \
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(                                                 \
+            const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)(nb_) * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000); \
+        if (HYB) ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(                                       \
+            const_cast<char *>(reinterpret_cast<const char *>(p.wpk_split) + (size_t)(nb_) * nchunks * USC_BYTES), 0, 0x7fffffff, 0x00020000); \
+    } while (0)
+    // the multiplications of xi step x_: four fp32 MFMAs, or (hybrid step) the split of the A operand and three bf16 MFMAs
+    // through one accumulator, strictly back to back
+#define W4P_MULT(x_, slot_)                                                                         \
+    do {                                                                                            \
+        if (W4P_HYB(x_)) {                                                                          \
+            unsigned wa__[6];                                                                       \
+            w4h_split(av[(x_) % 3], wa__);                                                          \
+            const u32x4 bq__ = __builtin_bit_cast(u32x4, bv[slot_]);                                \
+            u32x4 a_mh = {wa__[0], wa__[1], wa__[2], wa__[3]};                                      \
+            u32x4 a_hl = {wa__[2], wa__[3], wa__[4], wa__[5]};                                      \
+            u32x4 b_hl = {bq__[2], bq__[3], bl[slot_][0], bl[slot_][1]};                            \
+            asm volatile("" : "+v"(a_mh), "+v"(a_hl), "+v"(b_hl));                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, bq__), acc[x_], 0, 0, 0); \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq__), acc[x_], 0, 0, 0); \
+            acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl), acc[x_], 0, 0, 0); \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+                acc[x_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(x_) % 3][j], bv[slot_][j], acc[x_], 0, 0, 0); \
+        }                                                                                           \
+    } while (0)
 
 #if B2F_WINO_TRACE
     const int trp_slot = blockIdx.x == 40 ? 0 : blockIdx.x == 41 ? 1 : -1;
@@ -831,8 +899,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     for (int s = 0; s < 8; ++s) { W4_T_READ(s, 0); W4_T_FMA(s, 0); }
     __syncthreads();
 
-    w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)cur_nb * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000);
+    W4P_RSRC_U(cur_nb);
     W4P_LOAD_U(0, 0, 0); W4P_LOAD_U(1, 0, 1); W4P_LOAD_U(2, 0, 2); W4P_LOAD_U(3, 0, 3); W4P_LOAD_U(4, 0, 4);
     for (;;) {
         // ---- start of a tile: V[par] holds Tr(0), raw buffer par ^ 1 holds chunk 1, chunk 2 is in flight in sr, the
@@ -891,8 +958,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
                 if (x == 8) av[1] = W4_A_READ(Vn + 128);                                            \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][j], bv[(9 * (PH_) + x) % 6][j], acc[x], 0, 0, 0); \
+            W4P_MULT(x, (9 * (PH_) + x) % 6);                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (B2F_WINO4_ABLATE & 1) {                                                             \
                 if (x == 6) { if (!(B2F_WINO4_ABLATE & 2)) W4P_WRITE_RAW(pc); __builtin_amdgcn_sched_barrier(0); __syncthreads(); if (!(LAST_)) W4P_LOAD_STREAM(); } \
@@ -1027,8 +1093,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         W4P_PASS(1, );
         W4P_PASS(2, );
         W4P_PASS(3,
-                 w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                     const_cast<char *>(reinterpret_cast<const char *>(p.wpk) + (size_t)nxt_nb * nchunks * U_F4 * 16), 0, 0x7fffffff, 0x00020000);
+                 W4P_RSRC_U(nxt_nb);
                  W4P_LOAD_U(0, 0, 0); W4P_LOAD_U(1, 0, 1); W4P_LOAD_U(2, 0, 2); W4P_LOAD_U(3, 0, 3); W4P_LOAD_U(4, 0, 4););
 #undef W4P_PASS
 #undef W4P_LDS_BARRIER
@@ -1210,6 +1275,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #undef W4Q_LOAD_U
     }
 #undef W4P_LOAD_U
+#undef W4P_MULT
+#undef W4P_RSRC_U
+#undef W4P_HYB
 #undef W4P_WRITE_RAW
 #undef W4P_LOAD_STREAM
 #undef W4P_RSRC
@@ -1271,6 +1339,23 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
                 if (e != hipSuccess) return e;
                 pattr_done = true;
+            }
+            // hybrid forms (two-N-tile blocks with the split packing): p.w4_hybrid = number of bf16 steps per wave
+            if (NTV == 2 && p.wpk_split && p.w4_hybrid > 0) {
+                auto go = [&](auto kern) -> hipError_t {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kern, dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
+                    return hipGetLastError();
+                };
+                switch (p.w4_hybrid) {
+                case 2: return go(&conv3x3_wino4p<2, 0x044>);        // steps 2, 6
+                case 3: return go(&conv3x3_wino4p<2, 0x092>);        // steps 1, 4, 7
+                case 4: return go(&conv3x3_wino4p<2, 0x0AA>);        // steps 1, 3, 5, 7
+                case 5: return go(&conv3x3_wino4p<2, 0x155>);        // steps 0, 2, 4, 6, 8
+                case 6: return go(&conv3x3_wino4p<2, 0x16D>);        // all but 1, 4, 7
+                default: return go(&conv3x3_wino4p<2, 0x1FF>);       // every step
+                }
             }
             hipLaunchKernelGGL((conv3x3_wino4p<NTV>), dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
 #if B2F_WINO_TRACE
@@ -1337,7 +1422,7 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
     hipError_t e = hipSuccess;
     // n-blocks with two full N tiles: on the bf16 matrix pipe with split operands when the layer carries that packing
     // (b2f_wino4s.hip; persistent form only, K loop of at least 4 chunks), else on the fp32 MFMA
-    if (n2 > 0 && p.w4_persist && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
+    if (n2 > 0 && p.w4_persist && p.w4_hybrid == 0 && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
     else if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
     if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino4_t<1>(p, nfull, 1, s);
     return e;

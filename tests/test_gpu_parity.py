@@ -129,6 +129,27 @@ def test_conv3x3_wino4_split_operands(hard, scale, ci, co, h, w, blocks):
     assert np.array_equal(got, got1)
 
 
+@pytest.mark.parametrize("k", [3, 4, 9])
+def test_conv3x3_wino4_hybrid_steps(hard, k):
+    """Option wino4_hybrid = k: k of a wave's nine xi steps of the persistent F(4x4) kernel on the bf16 pipe with split operands,
+    the others on the fp32 MFMA (an experiment kept as an option: measured no faster).  Same accuracy claim as wino4_split."""
+    import torch
+    ci, co, h, w = 200, 128, 33, 65
+    r = _rng(900 + k)
+    x = r.standard_normal((2, ci, h, w), dtype=np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = r.standard_normal(co, dtype=np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
+    exp = torch.where(y > 0, y, 0.2 * y).numpy()
+    with hard.options(wino4_persistent=5):
+        f32 = ops.conv3x3(hard, x, wt, b, 1, True)
+        with hard.options(wino4_hybrid=k):
+            got = ops.conv3x3(hard, x, wt, b, 1, True)
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert not np.array_equal(got, f32)
+    assert es.max() <= 1.5e-4 and es.mean() < 5e-6 and es.mean() <= 1.25 * ef.mean()
+
+
 @pytest.mark.parametrize("scale", [1e-3, 30.0, 1e3])
 @pytest.mark.parametrize("ci,co,h,w", [(128, 128, 33, 65), (200, 96, 40, 70)])
 def test_conv3x3_wino4_activation_scale(hard, scale, ci, co, h, w):

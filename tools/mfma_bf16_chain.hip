@@ -60,6 +60,14 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, long long *cyc)
             _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile("v_add_f32 %0, %0, %0" : "+v"(v[q]));
             _Pragma("unroll") for (int q = 0; q < 6; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(u[q]) : "v"(v[q]));
             __builtin_amdgcn_sched_barrier(0); } }
+        // fp32 MFMA next to bf16 MFMA: mode 16 = 27 fp32 MFMAs (v_mfma_f32_32x32x2_f32) only; mode 17 = per accumulator 4 fp32 MFMAs,
+        // then on the next accumulator 3 bf16 MFMAs (9 x (4 + 3)... counted as 27 "units"); mode 18 = waves 0-3 fp32 only, waves 4-7 bf16 only
+        if (MODE == 16) { _Pragma("unroll") for (int i = 0; i < 27; ++i) acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i % 12], v[(i + 1) % 12], acc[i % 9], 0, 0, 0); }
+        if (MODE == 17) { _Pragma("unroll") for (int i = 0; i < 9; ++i) {
+            if (i & 1) { M(i); M(i); M(i); }
+            else { _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], v[j + 1], acc[i], 0, 0, 0); } } }
+        if (MODE == 18) { if (threadIdx.x < 256) { _Pragma("unroll") for (int i = 0; i < 27; ++i) acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i % 12], v[(i + 1) % 12], acc[i % 9], 0, 0, 0); }
+                          else { _Pragma("unroll") for (int i = 0; i < 27; ++i) M(i % 9); } }
         __builtin_amdgcn_sched_barrier(0);
     }
     const long long t1 = clock64();
@@ -112,5 +120,8 @@ int main()
     run<13>("chains of 3, then 12 v_lshlrev_b32");
     run<14>("chains of 3, then the split's 24 (6 cvt_pk, 8 and/shift, 4 pk_add, 6 mov)");
     run<15>("chains of 3, then the split's 28 with v_add instead of pk_add");
+    run<16>("27 fp32 MFMAs (32x32x2) per iteration, no bf16 (TFLOP/s column is meaningless: 1/8 of the MACs)");
+    run<17>("5 x 4 fp32 MFMAs + 4 x 3 bf16 MFMAs per iteration, alternating accumulators");
+    run<18>("512 threads only: waves 0-3 27 fp32 MFMAs, waves 4-7 27 bf16 MFMAs (do the two kinds overlap on a SIMD?)");
     return 0;
 }

@@ -11,6 +11,7 @@ from back2future_amd import back2future, ops
 m = back2future.Model("random:hard:1:1.0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+hyb = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # > 0: check the hybrid form (wino4_hybrid = that many bf16 steps) instead of wino4_split
 worst = [0.0, 0.0]
 mean = [0.0, 0.0]
 bad = 0
@@ -27,12 +28,14 @@ for it in range(n):
     m.set_option("wino4_min_pixels", 0)          # F(4x4) at every size
     G = int(rng.choice([2, 3, 5, 8, 17, 64]))
     m.set_option("wino4_persistent", G)
-    m.set_option("wino4_split", 0)
+    opt, val = ("wino4_hybrid", hyb) if hyb else ("wino4_split", 1)
+    m.set_option(opt, 0)
     f32 = ops.conv3x3(m, x, wt, b, 1, leaky)
-    m.set_option("wino4_split", 1)
+    m.set_option(opt, val)
     got = ops.conv3x3(m, x, wt, b, 1, leaky)
     m.set_option("wino4_persistent", 1)
     got1 = ops.conv3x3(m, x, wt, b, 1, leaky)
+    m.set_option(opt, 0)
     y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
     if leaky:
         y = torch.where(y > 0, y, 0.2 * y)
