@@ -282,10 +282,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
             bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)b2_off, (int)((c_) * UC_BYTES + (x_) * 1024), 0)); \
         }                                                                                           \
     } while (0)
+    // Anti-phase (W4S_ANTIPHASE): the two waves of a SIMD are w and w + 4, i.e. N tile 0 and N tile 1 of the same xi group, and run
+    // the same instruction stream from the same barrier -- in phase, so both want the matrix pipe at the same time and both do
+    // their VALU work at the same time.  The n = 0 waves split the A operand of a step right before its MFMAs, the n = 1 waves
+    // split it at the end of the PREVIOUS step: one wave of a SIMD is in its VALU stretch while the other is in its MFMAs.
+#ifndef W4S_STAGGER
+#define W4S_STAGGER 0
+#endif
+#ifndef W4S_ANTIPHASE
+#define W4S_ANTIPHASE 0      /* measured: the two code paths cost 269 spilled registers -- see W4S_STAGGER for the branch-free way */
+#endif
+#define W4S_SPLIT_A(i_)                                                                             \
+    do {                                                                                            \
+        if (!(B2F_W4S_ABLATE & 16)) w4s_split(av[(i_) % 3], wa);                                    \
+        else { _Pragma("unroll") for (int k = 0; k < 6; ++k) wa[k] = __builtin_bit_cast(unsigned, av[(i_) % 3][k & 3]); } \
+    } while (0)
 #define W4S_MFMA(x_, slot_)                                                                         \
     do {                                                                                            \
-        if (!(B2F_W4S_ABLATE & 16)) w4s_split(av[(x_) % 3], wa);                                    \
-        else { _Pragma("unroll") for (int k = 0; k < 6; ++k) wa[k] = __builtin_bit_cast(unsigned, av[(x_) % 3][k & 3]); } \
+        if (!W4S_ANTIPHASE || n == 0) W4S_SPLIT_A(x_);                                              \
         if (!(B2F_W4S_ABLATE & 8)) {                                                                \
             u32x4 a_mh = {wa[0], wa[1], wa[2], wa[3]};                                              \
             u32x4 a_hl = {wa[2], wa[3], wa[4], wa[5]};                                              \
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
             acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl), acc[x_], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
+        if (W4S_ANTIPHASE && n != 0) W4S_SPLIT_A((x_) + 1);                                         \
     } while (0)
     // the per-lane constants of the main loop, recomputed from the hardware lane id at the start of every tile: held across the
     // output stage they would be spilled, and a spill reload waits (vmcnt counts in order) for the output stores
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
         W4S_T_READ(2, par ^ 1);
         av[0] = Vb[par * VSTRIDE + a_off];
         av[1] = Vb[par * VSTRIDE + a_off + 64];
+        if (W4S_ANTIPHASE && n != 0) W4S_SPLIT_A(0);
 #pragma unroll
         for (int x = 0; x < 9; ++x)
 #pragma unroll
@@ -389,6 +405,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
                 W4S_WRITE_RAW(pc);                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 __syncthreads();                                                                    \
+                /* the two waves of a SIMD (w, w + 4) leave the barrier together and run the same stream in phase: both */ \
+                /* want the matrix pipe at once, both do their VALU stretch at once.  The n = 1 waves sleep W4S_STAGGER */ \
+                /* x 64 cycles here, once per chunk, so that one wave's MFMAs meet the other's VALU work */ \
+                if (W4S_STAGGER > 0 && n != 0) __builtin_amdgcn_s_sleep(W4S_STAGGER);                \
                 W4S_T_READ(0, pc);                                                                  \
                 if (!(LAST_)) W4S_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
             } else if (x == 7) {                                                                    \
