@@ -184,6 +184,11 @@ int pack_all(b2f_ctx *c, const float *flat)
             total += wino_wpk_floats(chunks, p.nt2, p.nblk2);
             p.b_off2 = total;
             total += (size_t)p.nblk2 * p.nt2 * 32;
+            if (c->wino2_split) {
+                total = (total + 3) & ~(size_t)3;
+                p.w_off4 = total;
+                total += wino2s_wpk_floats(chunks, p.nblk);
+            }
             if (c->wino4_split || c->wino4_hybrid) { // only while an option that reads it is on: 1.5x the F(4x4) packing
                 total = (total + 3) & ~(size_t)3;    // 16-byte aligned: the split weights are read with dwordx4 loads
                 p.w_off3 = total;
@@ -211,6 +216,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                                host.data() + p.w_off, host.data() + p.b_off);
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt2, p.nblk2,
                               host.data() + p.w_off2, host.data() + p.b_off2);
+            if (p.w_off4) wino2s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off4);
             if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
         } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
@@ -377,6 +383,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.w4_persist = c->wino4_persistent;
     L.wpk_split = (mode == 4 && (c->wino4_split || c->wino4_hybrid) && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
     L.w4_hybrid = c->wino4_hybrid;
+    L.wpk_split2 = (mode == 4 && c->wino2_split && p.w_off4) ? c->wpk_dev + p.w_off4 : nullptr;
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
@@ -750,6 +757,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
+        c->wino2_split = (int)env_int("B2F_WINO2_SPLIT", c->wino2_split);
         c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
         c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
@@ -859,6 +867,14 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
+    else if (!strcmp(key, "wino2_split")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        const bool had = c->wino2_split != 0;
+        c->wino2_split = value;
+        if (had != (value != 0)) CHK(b2f_commit_weights(c));
+    }
     else if (!strcmp(key, "wino4_split") || !strcmp(key, "wino4_hybrid")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -913,6 +929,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "wino4_split") *value = c->wino4_split;
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
+    else if (k == "wino2_split") *value = c->wino2_split;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
@@ -1288,7 +1305,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     else if (wino == 5) c16s2_pack_weights(wt, bias, Ci, nullptr, wpk.data(), bpk.data());
     else if (wino == 2) wino_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
     else conv_pack_weights(wt, bias, Co, Ci, nullptr, chunks, nt, nblk, wpk.data(), bpk.data());
-    DevBuf dpl, dx, dw, db, dy, dyp, dws;
+    DevBuf dpl, dx, dw, db, dy, dyp, dws, dws2;
     const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
     CHK(dpl.alloc(nx)); CHK(dx.alloc(nxp)); CHK(dw.alloc(wpk.size())); CHK(db.alloc(bpk.size())); CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
     if (wino == 4 && (c->wino4_split || c->wino4_hybrid)) {
@@ -1314,6 +1331,13 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.w4_persist = c->wino4_persistent;
     L.wpk_split = dws.p;
     L.w4_hybrid = c->wino4_hybrid;
+    if (wino == 4 && c->wino2_split) {
+        std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
+        wino2s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
+        CHK(dws2.alloc(wps.size()));
+        HIPCHK(hipMemcpy(dws2.p, wps.data(), wps.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.wpk_split2 = dws2.p;
+    }
     if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

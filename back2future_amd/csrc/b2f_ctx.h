@@ -39,6 +39,7 @@ struct PackedConv {
     size_t w_off2 = 0, b_off2 = 0;
     // ... and the weights split into three bf16 terms for the kernel on the bf16 matrix pipe (b2f_wino4s.hip); 0 = none
     size_t w_off3 = 0;
+    size_t w_off4 = 0;             // F(2x2) split packing (b2f_wino2s.hip); 0 = none
 };
 
 struct ProfEvent {
@@ -228,6 +229,8 @@ struct b2f_ctx {
     int corr_variant = -1;         // warp + cost volume: -1 auto, 0 regular, 1 latency variant (bit-identical results)
     int op_wino_split = 0;         // b2f_op_conv3x3: F(2x2) kernel with one block per 32-output N tile (tests)
     int profile_layers = 0;        // one profile row per (layer shape, map size)
+    int wino2_split = 0;           // F(4x4)-class layers, blocks of 64 outputs: 1 = Winograd F(2x2) on the bf16 matrix pipe with exactly split
+                                   // fp32 operands (b2f_wino2s.hip) on maps of at least wino4_min_pixels pixels
     int wino4_hybrid = 0;          // F(4x4) two-N-tile blocks: this many of a wave's nine xi steps on the bf16 pipe with split operands (needs the
                                    // split packing: setting it > 0 packs it); 0 = all on the fp32 MFMA
     int wino4_split = 0;           // F(4x4) layers with two full N tiles per block: 1 = on the bf16 matrix pipe with exactly split fp32 operands

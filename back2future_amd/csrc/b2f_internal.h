@@ -56,6 +56,7 @@ struct ConvLaunch {
     int w4_persist = 1;        // F(4x4) kernel: persistent blocks (one per CU) when the launch has at least two tiles per CU
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
     int w4_hybrid = 0;                 // F(4x4) persistent two-N-tile kernel: xi steps per wave that run on the bf16 pipe with split operands (0 = none)
+    const void *wpk_split2 = nullptr;  // F(2x2) kernel on the bf16 pipe (b2f_wino2s.hip): its split weights, or null
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
@@ -94,6 +95,11 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s);
 bool wino4s_supported(const ConvLaunch &p);
 hipError_t launch_conv3x3_wino4s(const ConvLaunch &p, int nb0, int nblk, hipStream_t s);
 size_t wino4s_wpk_floats(int cin_chunks, int nblk);
+// Winograd F(2x2) on the bf16 matrix pipe with split operands (b2f_wino2s.hip): 64 tiles x 64 outputs per block
+bool wino2s_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_wino2s(const ConvLaunch &p, int nb0, int nblk, hipStream_t s);
+size_t wino2s_wpk_floats(int cin_chunks, int nblk);
+void wino2s_pack_weights(const float *w, int Co, int Ci, const int *cin_map, int cin_chunks, int nblk, float *wpk);
 void wino4s_pack_weights(const float *w, int Co, int Ci, const int *cin_map, int cin_chunks, int nblk, float *wpk);
 int wino4_nblk(int cout);
 size_t wino4_wpk_floats(int cin_chunks, int nblk);

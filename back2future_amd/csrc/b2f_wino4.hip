@@ -52,9 +52,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // the VALU to the other wave, at the price of ~26 VALU instructions for the split.
 __device__ __forceinline__ unsigned w4h_pk(float a, float b)
 {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    // one v_cvt_pk_bf16_f32; NOT inline asm: the compiler must see the instruction to keep the VALU-write -> MFMA-read
+    // wait states (an asm statement two instructions ahead of the MFMA that read its result gave garbage)
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(pk_f32x2{a, b}, pk_bf16x2));
 }
 // fp32 quad -> window [m01 m23 | h01 h23 | l01 l23] of bf16 pairs (round to nearest even; x = h + m + l exactly)
 __device__ __forceinline__ void w4h_split(const f32x4 v, unsigned (&w)[6])
@@ -869,8 +871,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     long long *trp_buf = p.trace + (trp_on ? (trp_slot * 2 + (wave >> 2)) * 160 : 0);
     int trp_tile = 0;
 #define W4P_T(k_) do { if (trp_on && trp_tile < 12) trp_buf[trp_tile * 12 + (k_)] = clock64(); } while (0)
+    // step-level stamps of tile 3, chunks 8..11 (4 per xi step: step start | before the multiplications | after them | after the
+    // transform slice), kept in the spare LDS behind the kernel's buffers and copied out after the tile
+    long long *ts_lds = reinterpret_cast<long long *>(smem + P_LDS_BYTES) + (wave >> 2) * 144;
+#define W4P_TS(c_, x_, k_) do { if (trp_on && trp_tile == 3 && (c_) >= 8 && (c_) < 12) ts_lds[(((c_) - 8) * 9 + (x_)) * 4 + (k_)] = clock64(); } while (0)
 #else
 #define W4P_T(k_) do {} while (0)
+#define W4P_TS(c_, x_, k_) do {} while (0)
 #endif
     // ---- first tile: prologue as in the one-tile kernel ----
     if ((int)blockIdx.x >= total) return;
@@ -942,6 +949,30 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
+    // Order inside a xi step (round 4, B2F_W4P_SCHED = 1).  The step trace of the round-3 order ([B load, A read] -> [4 MFMAs] ->
+    // [transform slice + its reads]; profiles/r04_wino4_step_trace.txt) shows a wave spending ~140 cycles issuing its loads, ~280
+    // multiplying and ~240 in the slice, one after the other: ~650 cycles per step for 256 cycles of matrix pipe, and two such waves
+    // per SIMD.  A wave is in-order, but after it has issued a fp32 MFMA it has 64 cycles in which instructions that need neither
+    // the matrix pipe nor the VALU (buffer loads, LDS reads / writes, SALU) issue for free.  So: the slice's VALU work FIRST (its
+    // rows were read a step ago), then the four MFMAs with the step's memory instructions between them --
+    //     slice VALU | MFMA 0 | rows of the next slice | MFMA 1 | B operand of step x + 5 | MFMA 2 | A operand of step x + 1 | MFMA 3
+#ifndef B2F_W4P_SCHED
+#define B2F_W4P_SCHED 1
+#endif
+#define W4P_STEP_LOAD_U(PH_, x_, LAST_)                                                             \
+    do {                                                                                            \
+        if ((x_) + 5 < 9) W4P_LOAD_U((9 * (PH_) + (x_) + 5) % 6, c, (x_) + 5);                      \
+        else if (!(LAST_)) W4P_LOAD_U((9 * (PH_) + (x_) + 5) % 6, c + 1, (x_) + 5 - 9);             \
+    } while (0)
+#define W4P_STEP_A_READS(x_)                                                                        \
+    do {                                                                                            \
+        if (!(B2F_WINO4_ABLATE & 16)) {                                                             \
+            if ((x_) >= 1 && (x_) <= 6) av[((x_) + 1) % 3] = W4_A_READ(Vc + ((x_) + 1) * 128);      \
+            if ((x_) == 6) av[8 % 3] = W4_A_READ(Vc + 8 * 128);                                     \
+            if ((x_) == 7) av[0] = W4_A_READ(Vn);                                                   \
+            if ((x_) == 8) av[1] = W4_A_READ(Vn + 128);                                             \
+        }                                                                                           \
+    } while (0)
 #define W4P_CHUNK(PH_, c_, LAST_)                                                                        \
     do {                                                                                            \
         const int c = (c_);                                                                         \
@@ -949,17 +980,50 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_off;               \
         const f32x2 *Vn = reinterpret_cast<const f32x2 *>(Vb + (pc ^ 1) * VSTRIDE) + a_off;         \
         _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
-            if (x + 5 < 9) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c, x + 5);                           \
-            else if (!(LAST_)) W4P_LOAD_U((9 * (PH_) + x + 5) % 6, c + 1, x + 5 - 9);               \
-            if (!(B2F_WINO4_ABLATE & 16)) {                                                         \
-                if (x >= 1 && x <= 6) av[(x + 1) % 3] = W4_A_READ(Vc + (x + 1) * 128);              \
-                if (x == 6) av[8 % 3] = W4_A_READ(Vc + 8 * 128);                                    \
-                if (x == 7) av[0] = W4_A_READ(Vn);                                                  \
-                if (x == 8) av[1] = W4_A_READ(Vn + 128);                                            \
-            }                                                                                       \
+            W4P_TS(c, x, 0);                                                                        \
+            if (B2F_W4P_SCHED && !W4P_HYB(x) && !(B2F_WINO4_ABLATE & 1)) {                          \
+                /* ---- interleaved order ---- */                                                   \
+                if (x < 6) W4_T_FMA(x + 2, pc ^ 1);                                                 \
+                else if (x == 7) W4_T_FMA(0, 0);                                                    \
+                else if (x == 8) W4_T_FMA(1, 0);                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 1);                                                                    \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][0], bv[(9 * (PH_) + x) % 6][0], acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                /* rows of the next slice first: they are needed soonest (at the start of the next step) */ \
+                if (x < 6) { if (x + 3 < 8) W4_T_READ(x + 3, pc ^ 1); }                             \
+                else if (x == 7) W4_T_READ(1, pc);                                                  \
+                else if (x == 8) W4_T_READ(2, pc);                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][1], bv[(9 * (PH_) + x) % 6][1], acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_STEP_LOAD_U(PH_, x, LAST_);                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][2], bv[(9 * (PH_) + x) % 6][2], acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_STEP_A_READS(x);                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][3], bv[(9 * (PH_) + x) % 6][3], acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 2);                                                                    \
+                if (x == 6) {                                                                       \
+                    if (!(B2F_WINO4_ABLATE & 2)) W4P_WRITE_RAW(pc);                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                              \
+                    __syncthreads();                                                                \
+                    W4_T_READ(0, pc);                                                               \
+                    if (!(LAST_)) W4P_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 3);                                                                    \
+            } else {                                                                                \
+            /* ---- round-3 order (hybrid steps, ablation builds, B2F_W4P_SCHED = 0) ---- */        \
+            W4P_STEP_LOAD_U(PH_, x, LAST_);                                                         \
+            W4P_STEP_A_READS(x);                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            W4P_TS(c, x, 1);                                                                        \
             W4P_MULT(x, (9 * (PH_) + x) % 6);                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            W4P_TS(c, x, 2);                                                                        \
             if (B2F_WINO4_ABLATE & 1) {                                                             \
                 if (x == 6) { if (!(B2F_WINO4_ABLATE & 2)) W4P_WRITE_RAW(pc); __builtin_amdgcn_sched_barrier(0); __syncthreads(); if (!(LAST_)) W4P_LOAD_STREAM(); } \
             } else if (x < 6) {                                                                     \
@@ -977,6 +1041,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
                 W4_T_FMA(1, 0); W4_T_READ(2, pc);                                                   \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            W4P_TS(c, x, 3);                                                                        \
+            }                                                                                       \
         }                                                                                           \
     } while (0)
         W4P_T(1);
@@ -994,6 +1060,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             if (!even) W4P_CHUNK(0, c2, true);
         }
 #undef W4P_CHUNK
+#undef W4P_STEP_LOAD_U
+#undef W4P_STEP_A_READS
         W4P_T(2);
 
         // ---- output: four passes (tile rows) through the exchange buffer = dead V buffer + gap ----
@@ -1101,6 +1169,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         // ---- next tile of this block: the one whose Tr(0) the last iteration left in V[pl ^ 1] ----
         par = pl ^ 1;
 #if B2F_WINO_TRACE
+        if (trp_on && trp_tile == 3)
+            for (int i = 0; i < 144; ++i) p.trace[1280 + (trp_slot * 2 + (wave >> 2)) * 144 + i] = ts_lds[i];
         ++trp_tile;
 #endif
         if (!has_next) break;
@@ -1285,6 +1355,30 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #undef W4P_DECODE
 }
 
+// profiling builds: step-level stamps of the persistent two-N-tile kernel (block 40, waves 0 and 4 = the two waves of SIMD 0,
+// tile 3, chunks 8..11): per xi step the cycles from the step's start to the multiplications, of the multiplications, of
+// the transform slice, and the step's start relative to the chunk's
+static void w4p_print_trace(bool on, long long *trace_dev, hipStream_t s)
+{
+    if (!on || !trace_dev) return;
+    std::vector<long long> h(32 * 160);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), trace_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 2; ++w) {
+        const long long *t = h.data() + 1280 + w * 144;
+        if (!t[0]) continue;
+        fprintf(stderr, "wino4p step trace, block 40 wave %d, tile 3: per chunk and xi step x: start (cycles since chunk 8 began) | loads + A reads | multiplications | transform slice\n", 4 * w);
+        for (int c = 0; c < 4; ++c) {
+            fprintf(stderr, "  chunk %2d:", 8 + c);
+            for (int x = 0; x < 9; ++x) {
+                const long long *u = t + (c * 9 + x) * 4;
+                fprintf(stderr, "  x%d +%5lld|%3lld|%4lld|%4lld", x, u[0] - t[0], u[1] - u[0], u[2] - u[1], u[3] - u[2]);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+}
+
 template <int NTV>
 static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
 {
@@ -1307,10 +1401,17 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     const int tr_want = getenv("B2F_WINO_TRACE") ? atoi(getenv("B2F_WINO_TRACE")) : 0;
     const bool do_trace = tr_want > 0 && traced < 1 && NTV == 2 && p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0) == (tr_want == 1 ? 16 : tr_want) && p.H * p.W >= 256 * 480;
     if (do_trace) {
-        if (!trace_dev) hipMalloc(&trace_dev, 32 * 160 * sizeof(long long));
+        if (!trace_dev) hipMalloc(&trace_dev, 32 * 160 * sizeof(long long));     // [0, 640) tile stamps, [1280, 1856) step stamps
         hipMemsetAsync(trace_dev, 0, 32 * 160 * sizeof(long long), s);
         q.trace = trace_dev;
     }
+#endif
+#if B2F_WINO_TRACE
+    const bool do_trace_flag = do_trace;
+    long long *trace_ptr = trace_dev;
+#else
+    const bool do_trace_flag = false;
+    long long *trace_ptr = nullptr;
 #endif
     const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
     q.nblk = nblk;                          // n-blocks of THIS launch (the kernel decodes them from the 1-D grid)
@@ -1336,17 +1437,19 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
         const int nchunks_p = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
         if (nchunks_p >= 4) {
             if (!pattr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino4p<NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES + 2304 * B2F_WINO_TRACE);
                 if (e != hipSuccess) return e;
                 pattr_done = true;
             }
             // hybrid forms (two-N-tile blocks with the split packing): p.w4_hybrid = number of bf16 steps per wave
             if (NTV == 2 && p.wpk_split && p.w4_hybrid > 0) {
                 auto go = [&](auto kern) -> hipError_t {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES + 2304 * B2F_WINO_TRACE);
                     if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(kern, dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
-                    return hipGetLastError();
+                    hipLaunchKernelGGL(kern, dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES + 2304 * B2F_WINO_TRACE, s, q);
+                    hipError_t le = hipGetLastError();
+                    w4p_print_trace(do_trace_flag, trace_ptr, s);
+                    return le;
                 };
                 switch (p.w4_hybrid) {
                 case 2: return go(&conv3x3_wino4p<2, 0x044>);        // steps 2, 6
@@ -1357,7 +1460,8 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 default: return go(&conv3x3_wino4p<2, 0x1FF>);       // every step
                 }
             }
-            hipLaunchKernelGGL((conv3x3_wino4p<NTV>), dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES, s, q);
+            hipLaunchKernelGGL((conv3x3_wino4p<NTV>), dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES + 2304 * B2F_WINO_TRACE, s, q);
+            w4p_print_trace(do_trace_flag, trace_ptr, s);
 #if B2F_WINO_TRACE
             if (do_trace) {
                 ++traced;
@@ -1422,7 +1526,9 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
     hipError_t e = hipSuccess;
     // n-blocks with two full N tiles: on the bf16 matrix pipe with split operands when the layer carries that packing
     // (b2f_wino4s.hip; persistent form only, K loop of at least 4 chunks), else on the fp32 MFMA
-    if (n2 > 0 && p.w4_persist && p.w4_hybrid == 0 && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
+    // blocks of 64 outputs: Winograd F(2x2) on the bf16 matrix pipe with split operands when the layer carries that packing
+    if (n2 > 0 && wino2s_supported(p)) e = launch_conv3x3_wino2s(p, 0, n2, s);
+    else if (n2 > 0 && p.w4_persist && p.w4_hybrid == 0 && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
     else if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
     if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino4_t<1>(p, nfull, 1, s);
     return e;

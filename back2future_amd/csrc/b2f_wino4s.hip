@@ -70,9 +70,11 @@ __device__ __host__ constexpr int colpos(int p) { return (p & 3) * 9 + (p >> 2);
 // them (tools/mfma_bf16_chain.hip); this file is compiled with -fno-slp-vectorize so that the compiler does not re-pack them.
 __device__ __forceinline__ unsigned w4s_pk(float a, float b)
 {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    // one v_cvt_pk_bf16_f32; NOT inline asm: the compiler must see the instruction to keep the VALU-write -> MFMA-read
+    // wait states (an asm statement two instructions ahead of the MFMA that read its result gave garbage)
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(pk_f32x2{a, b}, pk_bf16x2));
 }
 __device__ __forceinline__ void w4s_split(const f32x4 v, unsigned (&w)[6])
 {
@@ -278,8 +280,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
 #define W4S_LOAD_U(slot_, c_, x_)                                                                   \
     do {                                                                                            \
         if (!(B2F_W4S_ABLATE & 4)) {                                                                \
-            bq[slot_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b4_off, (int)((c_) * UC_BYTES + (x_) * 2048), 0)); \
-            bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)b2_off, (int)((c_) * UC_BYTES + (x_) * 1024), 0)); \
+            /* ablate 32: every chunk reads chunk 0's weights (always cache-hot: is B latency a matter of L2 misses?) */ \
+            bq[slot_] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b4_off, (int)(((B2F_W4S_ABLATE & 32) ? 0 : (c_)) * UC_BYTES + (x_) * 2048), 0)); \
+            bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)b2_off, (int)(((B2F_W4S_ABLATE & 32) ? 0 : (c_)) * UC_BYTES + (x_) * 1024), 0)); \
         }                                                                                           \
     } while (0)
     // Anti-phase (W4S_ANTIPHASE): the two waves of a SIMD are w and w + 4, i.e. N tile 0 and N tile 1 of the same xi group, and run
@@ -383,6 +386,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
         //                xi step  6    : raw(c+2) -> LDS, A of xi 7, 8 fetched, BARRIER
         //                xi steps 7, 8 : A of xi 0, 1 of chunk c+1, slices 0, 1 of Tr(c+2); global loads of raw(c+3)
         // LAST_ = the tile's last chunk: no B operands of a following chunk (fetched under the last output pass instead)
+    // Order inside a xi step (W4S_SCHED = 1, from the step trace of the fp32 kernel, profiles/r04_wino4_step_trace.txt: an
+    // in-order wave that issues its loads, then multiplies, then runs its transform slice spends ~650 cycles per step on 96 cycles of
+    // matrix pipe): all of the step's VALU work first -- the transform slice (rows read a step ago) and the split of the A operand
+    // (read a step ago) -- then the three MFMAs with the step's memory instructions between them:
+    //     slice VALU, split | MFMA 0 | rows of the next slice | MFMA 1 | B operand of step x + LA | MFMA 2 | A operand of step x + 1
+    // While this wave is in its VALU stretch the other wave of the SIMD can be in its MFMAs (the bf16 pipe does not block the VALU).
+#ifndef W4S_SCHED
+#define W4S_SCHED 1
+#endif
+#define W4S_STEP_LOAD_U(PH_, x_, LAST_)                                                             \
+    do {                                                                                            \
+        if ((x_) + W4S_LA < 9) W4S_LOAD_U((9 * (PH_) + (x_) + W4S_LA) % 6, c, (x_) + W4S_LA);       \
+        else if (!(LAST_)) W4S_LOAD_U((9 * (PH_) + (x_) + W4S_LA) % 6, c + 1, (x_) + W4S_LA - 9);   \
+    } while (0)
+#define W4S_STEP_A_READS(x_)                                                                        \
+    do {                                                                                            \
+        if ((x_) >= 1 && (x_) <= 6) av[((x_) + 1) % 3] = Vc[((x_) + 1) * 64];                       \
+        if ((x_) == 6) av[8 % 3] = Vc[8 * 64];                                                      \
+        if ((x_) == 7) av[0] = Vn[0];                                                               \
+        if ((x_) == 8) av[1] = Vn[64];                                                              \
+    } while (0)
 #define W4S_CHUNK(PH_, c_, LAST_)                                                                   \
     do {                                                                                            \
         const int c = (c_);                                                                         \
@@ -390,12 +414,42 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
         const f32x4 *Vc = Vb + pc * VSTRIDE + a_off;                                                \
         const f32x4 *Vn = Vb + (pc ^ 1) * VSTRIDE + a_off;                                          \
         _Pragma("unroll") for (int x = 0; x < 9; ++x) {                                             \
-            if (x + W4S_LA < 9) W4S_LOAD_U((9 * (PH_) + x + W4S_LA) % 6, c, x + W4S_LA);            \
-            else if (!(LAST_)) W4S_LOAD_U((9 * (PH_) + x + W4S_LA) % 6, c + 1, x + W4S_LA - 9);     \
-            if (x >= 1 && x <= 6) av[(x + 1) % 3] = Vc[(x + 1) * 64];                               \
-            if (x == 6) av[8 % 3] = Vc[8 * 64];                                                     \
-            if (x == 7) av[0] = Vn[0];                                                              \
-            if (x == 8) av[1] = Vn[64];                                                             \
+            if (W4S_SCHED && !(B2F_W4S_ABLATE & 8)) {                                               \
+                const int slot = (9 * (PH_) + x) % 6;                                               \
+                if (x < 6) W4S_T_FMA(x + 2, pc ^ 1);                                                \
+                else if (x == 7) W4S_T_FMA(0, 0);                                                   \
+                else if (x == 8) W4S_T_FMA(1, 0);                                                   \
+                W4S_SPLIT_A(x);                                                                     \
+                u32x4 a_mh = {wa[0], wa[1], wa[2], wa[3]};                                          \
+                u32x4 a_hl = {wa[2], wa[3], wa[4], wa[5]};                                          \
+                u32x4 b_hl = {bq[slot][2], bq[slot][3], bl[slot][0], bl[slot][1]};                  \
+                asm volatile("" : "+v"(a_mh), "+v"(a_hl), "+v"(b_hl));                              \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, bq[slot]), acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                if (x < 6) { if (x + 3 < 8) W4S_T_READ(x + 3, pc ^ 1); }                            \
+                else if (x == 7) W4S_T_READ(1, pc);                                                 \
+                else if (x == 8) W4S_T_READ(2, pc);                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq[slot]), acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4S_STEP_LOAD_U(PH_, x, LAST_);                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl), acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4S_STEP_A_READS(x);                                                                \
+                if (x == 6) {                                                                       \
+                    W4S_WRITE_RAW(pc);                                                              \
+                    __builtin_amdgcn_sched_barrier(0);                                              \
+                    __syncthreads();                                                                \
+                    if (W4S_STAGGER > 0 && n != 0) __builtin_amdgcn_s_sleep(W4S_STAGGER);            \
+                    W4S_T_READ(0, pc);                                                              \
+                    if (!(LAST_)) W4S_LOAD_STREAM();   /* the last chunk's is issued in the output stage */ \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            } else {                                                                                \
+            W4S_STEP_LOAD_U(PH_, x, LAST_);                                                         \
+            W4S_STEP_A_READS(x);                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             W4S_MFMA(x, (9 * (PH_) + x) % 6);                                                       \
             if (x < 6) {                                                                            \
@@ -417,6 +471,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4s(const ConvLaunch p)
                 W4S_T_FMA(1, 0); W4S_T_READ(2, pc);                                                 \
             }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            }                                                                                       \
         }                                                                                           \
     } while (0)
         {

@@ -8,6 +8,10 @@ from back2future_amd import back2future, ops
 a = [int(v) for v in sys.argv[1:]] + [128, 128, 128, 240, 4, 3][len(sys.argv) - 1:]
 ci, co, h, w, B, reps = a
 m = back2future.Model("random:hard:1:1.0")
+import os
+for kv in os.environ.get("B2F_ONE_LAYER_OPTS", "").split(","):
+    if "=" in kv:
+        m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 rng = np.random.default_rng(0)
 x = rng.standard_normal((B, ci, h, w), dtype=np.float32)
 wt = (rng.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)

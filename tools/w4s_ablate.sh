@@ -6,5 +6,5 @@ for a in 0 1 2 4 6 8 16; do
   lib=back2future_amd/libb2f_w4sabl$a.so
   [ $a = 0 ] && lib=back2future_amd/libb2f.so
   [ -f $lib ] || continue
-  echo "ablate=$a: $(B2F_LIB=$PWD/$lib python tools/layer_prof.py --batch 8 --filter convW4 2>/dev/null | grep -E '200to128_256|128to128_256|96to64_256' | tr -s ' ' | tr '\n' ';')"
+  echo "ablate=$a: $(B2F_LIB=$PWD/$lib python tools/layer_prof.py --batch 8 --filter convW4 wino4_split=1 2>/dev/null | grep -E '200to128_256|128to128_256|96to64_256' | tr -s ' ' | tr '\n' ';')"
 done

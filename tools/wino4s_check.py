@@ -28,7 +28,7 @@ for it in range(n):
     m.set_option("wino4_min_pixels", 0)          # F(4x4) at every size
     G = int(rng.choice([2, 3, 5, 8, 17, 64]))
     m.set_option("wino4_persistent", G)
-    opt, val = ("wino4_hybrid", hyb) if hyb else ("wino4_split", 1)
+    opt, val = ("wino4_hybrid", hyb) if hyb > 0 else ("wino2_split", 1) if hyb < 0 else ("wino4_split", 1)   # hyb < 0: the F(2x2) split kernel
     m.set_option(opt, 0)
     f32 = ops.conv3x3(m, x, wt, b, 1, leaky)
     m.set_option(opt, val)
