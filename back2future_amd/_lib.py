@@ -71,6 +71,7 @@ SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int, c_float_p]),
     "b2f_op_conv3x3": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p,
                                  C.c_int, C.c_int, C.c_int, c_float_p]),
+    "b2f_op_conv_head16": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "b2f_op_upsample_flow2x": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_float_p]),
     "b2f_op_image_scale": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, c_float_p, C.c_int, C.c_int]),
 }

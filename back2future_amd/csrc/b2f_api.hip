@@ -384,10 +384,11 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.wpk_split = (mode == 4 && (c->wino4_split || c->wino4_hybrid) && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
     L.w4_hybrid = c->wino4_hybrid;
     L.wpk_split2 = (mode == 4 && c->wino2_split && p.w_off4) ? c->wpk_dev + p.w_off4 : nullptr;
+    L.bf16_direct = c->bf16_direct;
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? "C16" : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
         snprintf(name, sizeof name, mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
@@ -448,6 +449,7 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         HIPCHK(launch_pack_input((const float *)dev_in, unit, B, P.H, P.W, A + P.img, s));
     }
     // siamese feature pyramid, the three frames batched (shared weights, pwc.lua:169-211)
+    const bool head_fused = c->bf16_direct >= 2 && P.h[2] >= 4 && P.w[2] >= 4;   // level-2 conv 2 + level-3 conv 1 as one streaming kernel; cs[2] then holds the 32-channel level-3 map
     for (int l = 2; l <= 7; ++l) {
         const int hi = P.h[l - 1], wi = P.w[l - 1], ho = P.h[l], wo = P.w[l];
         const int Ci = (l == 2) ? kImgC : kFeat[l - 1], Co = kFeat[l];
@@ -455,9 +457,28 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
             Scope sc(c, s, "conv_first", cap);
             HIPCHK(launch_conv_first((const float *)dev_in, unit, B, P.H, P.W, c->wpk_dev + c->first_w_off,
                                      c->wpk_dev + c->first_b_off, A + P.tmp, s));
+        } else if (l == 3 && head_fused) {   // conv 1 of level 3 ran inside the fused head: its output sits in the (otherwise unused) cs[2] region
+            const ConvSeg in2f = cp8_seg(A + P.cs[2], Co, (size_t)ho * wo);
+            CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2f, 3 * B, ho, wo, 1, 1, A + P.cs[l]));
+            continue;
         } else {
             const ConvSeg in1 = cp8_seg(A + P.cs[l - 1], Ci, (size_t)hi * wi);
             CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 1), &in1, 3 * B, hi, wi, 2, 1, A + P.tmp));
+        }
+        if (l == 2 && head_fused) {   // level-2 conv 2 + level-3 conv 1 in one streaming kernel (b2f_head.hip)
+            const PackedConv &p1 = c->packed[find_conv(c, KIND_FEAT, 2, 2)], &p2 = c->packed[find_conv(c, KIND_FEAT, 3, 1)];
+            HeadLaunch hl;
+            hl.in = A + P.tmp; hl.in_img_stride = (long)((size_t)ho * wo * 16); hl.in_chunk_stride = (long)((size_t)ho * wo * 8); hl.in_pix_stride = 8;
+            hl.H1 = ho; hl.W1 = wo;
+            hl.w1 = c->wpk_dev + p1.w_off; hl.b1 = c->wpk_dev + p1.b_off; hl.w2 = c->wpk_dev + p2.w_off; hl.b2 = c->wpk_dev + p2.b_off;
+            hl.out = A + P.cs[2];
+            hl.Ho = P.h[3]; hl.Wo = P.w[3]; hl.nimg = 3 * B;
+            hl.out_img_stride = (long)((size_t)hl.Ho * hl.Wo * 32); hl.out_chunk_stride = (long)((size_t)hl.Ho * hl.Wo * 8); hl.out_pix_stride = 8;
+            char hname[48];
+            snprintf(hname, sizeof hname, c->profile_layers ? "convH16_16to32_%dx%d" : "conv_head16_bf16", ho, wo);
+            Scope sc(c, s, hname, cap);
+            HIPCHK(launch_conv_head16(hl, s));
+            continue;
         }
         const ConvSeg in2 = cp8_seg(A + P.tmp, Co, (size_t)ho * wo);
         CHK(run_conv(c, s, cap, find_conv(c, KIND_FEAT, l, 2), &in2, 3 * B, ho, wo, 1, 1, A + P.cs[l]));
@@ -758,6 +779,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
         c->wino2_split = (int)env_int("B2F_WINO2_SPLIT", c->wino2_split);
+        c->bf16_direct = (int)env_int("B2F_BF16_DIRECT", c->bf16_direct);
         c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
         c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
@@ -867,6 +889,7 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
+    else if (!strcmp(key, "bf16_direct")) c->bf16_direct = value;
     else if (!strcmp(key, "wino2_split")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -930,6 +953,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "wino4_split") *value = c->wino4_split;
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino2_split") *value = c->wino2_split;
+    else if (k == "bf16_direct") *value = c->bf16_direct;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
@@ -1331,6 +1355,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.w4_persist = c->wino4_persistent;
     L.wpk_split = dws.p;
     L.w4_hybrid = c->wino4_hybrid;
+    L.bf16_direct = c->bf16_direct;
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
         wino2s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
@@ -1350,5 +1375,40 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     return 0;
 }
 B2F_CATCH("b2f_op_conv3x3")
+
+int b2f_op_conv_head16(b2f_ctx *c, const float *x, int B, int H, int W, const float *w1, const float *b1, const float *w2,
+                       const float *b2, float *y) try
+{
+    if (!c || !x || !w1 || !b1 || !w2 || !b2 || !y) return fail("b2f_op_conv_head16: null argument");
+    if (B < 1 || H < 1 || W < 1) return fail("b2f_op_conv_head16: bad size");
+    HIPCHK(hipSetDevice(c->device));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    std::vector<float> p1(c16_wpk_floats()), pb1(32), p2(c16s2_wpk_floats()), pb2(32);
+    c16_pack_weights(w1, b1, 16, nullptr, p1.data(), pb1.data());
+    c16s2_pack_weights(w2, b2, 16, nullptr, p2.data(), pb2.data());
+    DevBuf dpl, dx, dw1, db1, dw2, db2, dy, dyp;
+    const size_t nx = (size_t)B * 16 * H * W, ny = (size_t)B * 32 * Ho * Wo;
+    CHK(dpl.alloc(nx)); CHK(dx.alloc(nx)); CHK(dw1.alloc(p1.size())); CHK(db1.alloc(32)); CHK(dw2.alloc(p2.size())); CHK(db2.alloc(32));
+    CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
+    HIPCHK(hipMemcpy(dpl.p, x, nx * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw1.p, p1.data(), p1.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db1.p, pb1.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw2.p, p2.data(), p2.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db2.p, pb2.data(), 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(launch_planar_to_nhwc(dpl.p, 16, B, H, W, dx.p, 16, c->stream));
+    HeadLaunch hl;
+    hl.in = dx.p; hl.in_img_stride = (long)((size_t)H * W * 16); hl.in_chunk_stride = 8; hl.in_pix_stride = 16;
+    hl.H1 = H; hl.W1 = W;
+    hl.w1 = dw1.p; hl.b1 = db1.p; hl.w2 = dw2.p; hl.b2 = db2.p;
+    hl.out = dy.p; hl.out_img_stride = (long)((size_t)Ho * Wo * 32); hl.out_chunk_stride = 8; hl.out_pix_stride = 32;
+    hl.Ho = Ho; hl.Wo = Wo; hl.nimg = B;
+    if (!head16_supported(hl)) return fail("b2f_op_conv_head16: unsupported shape");
+    HIPCHK(launch_conv_head16(hl, c->stream));
+    HIPCHK(launch_nhwc_to_planar(dy.p, 32, 32, B, Ho, Wo, dyp.p, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(y, dyp.p, ny * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+B2F_CATCH("b2f_op_conv_head16")
 
 }  // extern "C"

@@ -229,6 +229,8 @@ struct b2f_ctx {
     int corr_variant = -1;         // warp + cost volume: -1 auto, 0 regular, 1 latency variant (bit-identical results)
     int op_wino_split = 0;         // b2f_op_conv3x3: F(2x2) kernel with one block per 32-output N tile (tests)
     int profile_layers = 0;        // one profile row per (layer shape, map size)
+    int bf16_direct = 2;           // the 16-channel layers of the head on the bf16 matrix pipe with exactly split fp32 operands: 0 = fp32-MFMA kernels,
+                                   // 1 = the 16 -> 16 layer alone (b2f_conv16b.hip), 2 = 16 -> 16 + 16 -> 32 stride 2 fused, the map between them in LDS (b2f_head.hip)
     int wino2_split = 0;           // F(4x4)-class layers, blocks of 64 outputs: 1 = Winograd F(2x2) on the bf16 matrix pipe with exactly split
                                    // fp32 operands (b2f_wino2s.hip) on maps of at least wino4_min_pixels pixels
     int wino4_hybrid = 0;          // F(4x4) two-N-tile blocks: this many of a wave's nine xi steps on the bf16 pipe with split operands (needs the

@@ -57,6 +57,7 @@ struct ConvLaunch {
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
     int w4_hybrid = 0;                 // F(4x4) persistent two-N-tile kernel: xi steps per wave that run on the bf16 pipe with split operands (0 = none)
     const void *wpk_split2 = nullptr;  // F(2x2) kernel on the bf16 pipe (b2f_wino2s.hip): its split weights, or null
+    int bf16_direct = 0;               // direct 16-channel kernels on the bf16 pipe with split fp32 operands (b2f_conv16b.hip)
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
@@ -71,8 +72,26 @@ void conv_pack_weights(const float *w, const float *b, int Co, int Ci, const int
 // ---- 16 -> 16 stride-1 layer (level-2 convUnit): single-pass kernel on the 16x16x4 MFMA (b2f_conv16.hip),
 // weights [tap 9][kg 4][co 16][4]
 hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s);
+hipError_t launch_conv3x3_c16b(const ConvLaunch &p, hipStream_t s);   // the same layer on the bf16 pipe (ConvLaunch::bf16_direct)
 size_t c16_wpk_floats();
 void c16_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, float *wpk, float *bpk);
+// 16 -> 16 (stride 1) + 16 -> 32 (stride 2), both with LeakyReLU(0.2), as ONE streaming kernel on the bf16 pipe (b2f_head.hip): the
+// 16-channel map between them stays in LDS.  Weights: the c16 / c16s2 packings.
+struct HeadLaunch {
+    const float *in;                    // 16 channels, chunk-planar
+    long in_img_stride, in_chunk_stride;
+    int in_pix_stride;
+    int H1, W1;                         // size of the input = size of the intermediate
+    const float *w1, *b1, *w2, *b2;
+    float *out;                         // 32 channels at Ho x Wo
+    long out_img_stride, out_chunk_stride;
+    int out_pix_stride;
+    int Ho, Wo, nimg;
+    int rows_per_block, nsy, nsx;       // filled in by the launcher
+    long long *trace = nullptr;         // profiling builds only
+};
+bool head16_supported(const HeadLaunch &p);
+hipError_t launch_conv_head16(HeadLaunch p, hipStream_t s);
 // 16 -> 32 channels, stride 2 (mode 5): the same single-pass scheme
 bool c16s2_supported(const ConvLaunch &p);
 hipError_t launch_conv3x3_c16s2(const ConvLaunch &p, hipStream_t s);

@@ -51,6 +51,17 @@ def conv3x3(model, x, w, b, stride=1, leaky=False):
     return y
 
 
+def conv_head16(model, x, w1, b1, w2, b2):
+    """conv(16,16,s1) + LeakyReLU(0.2) + conv(16,32,s2) + LeakyReLU(0.2) in the fused streaming kernel (pwc.lua:60-62)."""
+    x, w1, b1, w2, b2 = _lib.f32(x), _lib.f32(w1), _lib.f32(b1), _lib.f32(w2), _lib.f32(b2)
+    B, ci, H, W = x.shape
+    assert ci == 16 and w1.shape == (16, 16, 3, 3) and w2.shape == (32, 16, 3, 3)
+    y = np.empty((B, 32, (H - 1) // 2 + 1, (W - 1) // 2 + 1), np.float32)
+    _lib.check(_lib.lib().b2f_op_conv_head16(_h(model), _lib.fptr(x), B, H, W, _lib.fptr(w1), _lib.fptr(b1), _lib.fptr(w2),
+                                             _lib.fptr(b2), _lib.fptr(y)))
+    return y
+
+
 def upsample_flow2x(model, x):
     x = _lib.f32(x)
     B, two, h, w = x.shape

@@ -66,13 +66,17 @@ def conv_layers(H, W):
     return out
 
 
-MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2"}
+MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2",
+              "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16"}
+BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
 
 
 def layer_kernels(model, step, torch):
     """Kernel class of every conv layer AS THE LIBRARY RAN IT: one eager pass with option profile_layers, whose rows are named
     conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
-    C16 = 16 -> 16 kernel, S16 = 16 -> 32 stride-2 kernel, D1 / D2 = direct kernel stride 1 / 2).  Returns {(cin_padded, cout, H_in, W_in): class}."""
+    C16 = 16 -> 16 kernel, S16 = 16 -> 32 stride-2 kernel, D1 / D2 = direct kernel stride 1 / 2, B16 = the 16 -> 16 layer on the bf16 pipe,
+    H16 = the fused head: 16 -> 16 and 16 -> 32 stride 2 in one kernel on the bf16 pipe, one row for both layers).
+    Returns {(cin_padded, cout, H_in, W_in): class}."""
     model.set_option("use_graph", 0)
     model.set_option("profile_layers", 1)
     model.set_option("profile", 1)
@@ -86,9 +90,11 @@ def layer_kernels(model, step, torch):
     import re
     out = {}
     for name, (ms, n) in rows.items():
-        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
         if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
             out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
+            if m.group(1) == "H16":  # the fused head also holds the 16 -> 16 layer in front of its 16 -> 32 one
+                out[(16, 16, int(m.group(4)), int(m.group(5)))] = MODE_CLASS["H16"]
     return out
 
 
@@ -103,7 +109,7 @@ def conv_flops_by_kernel(H, W, kernels):
         cop = (co + 31) // 32 * 32
         per_out = {"conv3x3_wino4": 36.0 / 16.0, "conv3x3_wino": 16.0 / 4.0}.get(k, 9.0)
         e = 2.0 * per_out * cip * cop
-        if k in ("conv_first", "conv3x3_narrow2"):
+        if k in ("conv_first", "conv3x3_narrow2") or k in BF16_PIPE:
             e = 0.0
         if k == "conv3x3_c16":
             e = 2.0 * 9.0 * 16 * 16
@@ -482,7 +488,10 @@ def main():
                                         "peak": 157.3, "unit": "TFLOP/s", "frac": e_all / 157.3, "executed_flop_per_step": ex,
                                         "effective_vs_direct": {"achieved": a_all, "x_peak": a_all / 157.3, "algorithmic_flop_per_step": flops},
                                         "traffic": tr.get("conv", {}).get("traffic_bytes"), "traffic_unit": "HBM bytes per step (PMC)",
-                                        "traffic_source": tr.get("file"), "ms_per_step": conv_ms}
+                                        "traffic_source": tr.get("file"), "ms_per_step": conv_ms,
+                                        "bf16_pipe_ms_per_step": sum(kms.get(k, 0.0) for k in BF16_PIPE),
+                                        "note": "kernels that multiply on the bf16 pipe with split fp32 operands (%s) count with their time and "
+                                                "their direct-convolution FLOPs but execute no fp32-MFMA FLOPs" % ", ".join(k for k in BF16_PIPE if k in kms)}
             cb = corr_bytes_per_px() * px
             g = cb / (corr_ms * 1e-3) / 1e9 if corr_ms > 0 else 0.0
             out["roofline_corrwarp"] = {"kernel": "warp_costvol (%d launches of a step)" % corr_n, "bound": "hbm",

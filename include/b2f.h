@@ -237,6 +237,12 @@ B2F_API int b2f_op_warp_costvol(b2f_ctx *ctx, const float *ref, const float *nbr
  * x: B x Ci x H x W, w: Co x Ci x 3 x 3, y: B x Co x Ho x Wo.                       */
 B2F_API int b2f_op_conv3x3(b2f_ctx *ctx, const float *x, int B, int Ci, int H, int W, const float *w,
                    const float *bias, int Co, int stride, int leaky, float *y);
+/* The two 16-channel layers of the head of the pyramid as the pipeline runs them with option bf16_direct = 2, in one kernel:
+ * nn.SpatialConvolution(16,16,3,3,1,1,1,1) + LeakyReLU(0.2) (pwc.lua:62, level-2 convUnit) followed by
+ * nn.SpatialConvolution(16,32,3,3,2,2,1,1) + LeakyReLU(0.2) (pwc.lua:60, level-3 convUnit).
+ * x: B x 16 x H x W, w1: 16 x 16 x 3 x 3, w2: 32 x 16 x 3 x 3, y: B x 32 x ceil(H/2) x ceil(W/2).                       */
+B2F_API int b2f_op_conv_head16(b2f_ctx *ctx, const float *x, int B, int H, int W, const float *w1, const float *b1,
+                       const float *w2, const float *b2, float *y);
 /* nn.SpatialUpSamplingBilinear(2) on a 2-channel flow field -- pwc.lua:360-381;
  * x: B x 2 x h x w -> y: B x 2 x 2h x 2w.                                            */
 B2F_API int b2f_op_upsample_flow2x(b2f_ctx *ctx, const float *x, int B, int h, int w, float *y);

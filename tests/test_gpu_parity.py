@@ -390,6 +390,71 @@ def test_compute_flow_with_split_operand_winograd(hard):
     assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+@pytest.mark.parametrize("B,h,w", [(1, 32, 60), (2, 37, 71), (3, 5, 9), (1, 130, 61), (1, 256, 64), (2, 16, 300)])
+def test_fused_head_on_the_bf16_pipe(hard, scale, B, h, w):
+    """b2f_op_conv_head16 = the kernel the default pipeline (option bf16_direct = 2) runs for conv(16,16,s1)+LeakyReLU -> conv(16,32,s2)+
+    LeakyReLU (pwc.lua:60-62): one streaming kernel, split fp32 operands on the bf16 matrix pipe, the 16-channel map kept in LDS.
+    Checked against the oracle's two convolutions and an fp64 reference: fp32-level accuracy (inside the bars of test_conv3x3 and
+    within 1.5x of the chained fp32-MFMA kernels' own error), strips / row blocks / odd sizes / image borders included."""
+    import torch
+    r = _rng(B * 1000 + h * 7 + w)
+    x = (r.standard_normal((B, 16, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    w1 = (r.standard_normal((16, 16, 3, 3), dtype=np.float32) / 12).astype(np.float32)
+    w2 = (r.standard_normal((32, 16, 3, 3), dtype=np.float32) / 12).astype(np.float32)
+    b1 = (r.standard_normal(16, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    b2 = (r.standard_normal(32, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    t = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w1).double(), torch.from_numpy(b1).double(), padding=1)
+    t = torch.where(t > 0, t, 0.2 * t)
+    t = torch.nn.functional.conv2d(t, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1, stride=2)
+    exp = torch.where(t > 0, t, 0.2 * t).numpy()
+    got = ops.conv_head16(hard, x, w1, b1, w2, b2)
+    with hard.options(bf16_direct=0):
+        f32 = ops.conv3x3(hard, ops.conv3x3(hard, x, w1, b1, 1, True), w2, b2, 2, True)
+    ora = O.conv3x3(O.conv3x3(x, w1, b1, 1, True), w2, b2, 2, True)
+    assert got.shape == exp.shape and np.isfinite(got).all()
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert es.max() <= 1e-4 * scale and es.mean() < 5e-6 * scale
+    assert es.max() <= 1.5 * ef.max() + 1e-6 * scale
+    assert np.abs(got - ora).max() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("B,h,w", [(1, 16, 32), (2, 37, 70), (3, 64, 33)])
+def test_conv16_on_the_bf16_pipe(hard, B, h, w):
+    """Option bf16_direct = 1: the 16 -> 16 layer alone on the bf16 pipe (b2f_conv16b.hip), same accuracy claim."""
+    import torch
+    r = _rng(B * 77 + h + w)
+    x = r.standard_normal((B, 16, h, w), dtype=np.float32)
+    wt = (r.standard_normal((16, 16, 3, 3), dtype=np.float32) / 12).astype(np.float32)
+    b = r.standard_normal(16, dtype=np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
+    exp = torch.where(y > 0, y, 0.2 * y).numpy()
+    with hard.options(bf16_direct=0):
+        f32 = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(bf16_direct=1):
+        got = ops.conv3x3(hard, x, wt, b, 1, True)
+    assert not np.array_equal(got, f32)
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert es.max() <= 1e-4 and es.max() <= 1.5 * ef.max() + 1e-6
+
+
+def test_compute_flow_head_kernels_agree(hard):
+    """The whole graph with the head of the pyramid on the fp32-MFMA kernels (bf16_direct = 0), with the 16 -> 16 layer on the bf16 pipe
+    (1) and with the fused head (2, the default): the same function within fp32 rounding, each inside the end-to-end bar."""
+    r = _rng(21)
+    H, Wd = 128, 256
+    ims = _triplet(r, H, Wd)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
+    flows = {}
+    for o in (0, 1, 2):
+        with hard.options(bf16_direct=o, host_graph=0):
+            flows[o], _, _ = hard.computeFlow(*ims)
+        assert np.abs(flows[o] - eflow).max() <= 1e-3
+    assert hard.get_option("bf16_direct") == 2
+    assert not np.array_equal(flows[0], flows[2]) and np.abs(flows[0] - flows[2]).max() < 2e-5
+    assert np.abs(flows[0] - flows[1]).max() < 2e-5
+
+
 def test_compute_flow_non_multiple_of_64(soft):
     """375 x 1242-style input: host-side image.scale to 320 x 1216-style size, nearest rescale back."""
     r = _rng(77)
