@@ -178,6 +178,13 @@ int pack_all(b2f_ctx *c, const float *flat)
                  : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
+        if ((p.wino == 0 || (p.wino == 4 && d.co <= 32)) && (d.co & 3) == 0) {   // direct layers (and 32-output Winograd-class ones): also packed for the kernel on the bf16 pipe
+            total = (total + 3) & ~(size_t)3;
+            p.w_off5 = total;
+            total += convb_wpk_floats(chunks, d.co);
+            p.b_off5 = total;
+            total += (size_t)convb_nblk(d.co) * 64;
+        }
         if (p.wino == 4) {
             wino_choose_tiles(d.co, &p.nt2, &p.nblk2);
             p.w_off2 = total;
@@ -216,6 +223,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                                host.data() + p.w_off, host.data() + p.b_off);
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt2, p.nblk2,
                               host.data() + p.w_off2, host.data() + p.b_off2);
+            if (p.w_off5) convb_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off5, host.data() + p.b_off5);
             if (p.w_off4) wino2s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off4);
             if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
         } else if (p.wino == 1)
@@ -228,9 +236,11 @@ int pack_all(b2f_ctx *c, const float *flat)
         else if (p.wino == 2)
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
                               host.data() + p.w_off, host.data() + p.b_off);
-        else
+        else {
             conv_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
                               host.data() + p.w_off, host.data() + p.b_off);
+            if (p.w_off5) convb_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off5, host.data() + p.b_off5);
+        }
     }
     if (c->wpk_floats != total) {
         if (c->wpk_dev) HIPCHK(hipFree(c->wpk_dev));
@@ -385,17 +395,20 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.w4_hybrid = c->wino4_hybrid;
     L.wpk_split2 = (mode == 4 && c->wino2_split && p.w_off4) ? c->wpk_dev + p.w_off4 : nullptr;
     L.bf16_direct = c->bf16_direct;
+    const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && c->bf16_conv >= 2 && stride == 1 && H * W >= c->bf16_conv_min_pixels));
+    if (bf6) { L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5; }
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
+        snprintf(name, sizeof name, bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
-    if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
+    if (bf6 && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, s));
+    else if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
     else if (mode == 3) HIPCHK(launch_conv3x3_c16(L, s));
     else if (mode == 5) HIPCHK(launch_conv3x3_c16s2(L, s));
@@ -780,6 +793,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
         c->wino2_split = (int)env_int("B2F_WINO2_SPLIT", c->wino2_split);
         c->bf16_direct = (int)env_int("B2F_BF16_DIRECT", c->bf16_direct);
+        c->bf16_conv = (int)env_int("B2F_BF16_CONV", c->bf16_conv);
         c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
         c->host_subbatch_pixels = env_int("B2F_HOST_SUBBATCH_PIXELS", c->host_subbatch_pixels);
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
@@ -890,6 +904,8 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
     else if (!strcmp(key, "bf16_direct")) c->bf16_direct = value;
+    else if (!strcmp(key, "bf16_conv")) c->bf16_conv = value;
+    else if (!strcmp(key, "bf16_conv_min_pixels")) c->bf16_conv_min_pixels = value;
     else if (!strcmp(key, "wino2_split")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -954,6 +970,8 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino2_split") *value = c->wino2_split;
     else if (k == "bf16_direct") *value = c->bf16_direct;
+    else if (k == "bf16_conv") *value = c->bf16_conv;
+    else if (k == "bf16_conv_min_pixels") *value = c->bf16_conv_min_pixels;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
@@ -1356,6 +1374,16 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.wpk_split = dws.p;
     L.w4_hybrid = c->wino4_hybrid;
     L.bf16_direct = c->bf16_direct;
+    DevBuf dw5, db5;
+    const bool bf6_op = (Co & 3) == 0 && ((wino == 0 && c->bf16_conv) || (wino == 4 && c->bf16_conv >= 2 && stride == 1 && Co <= 32 && H * W >= c->bf16_conv_min_pixels));
+    if (bf6_op) {
+        std::vector<float> w5(convb_wpk_floats(chunks, Co)), b5((size_t)convb_nblk(Co) * 64);
+        convb_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w5.data(), b5.data());
+        CHK(dw5.alloc(w5.size())); CHK(db5.alloc(b5.size()));
+        HIPCHK(hipMemcpy(dw5.p, w5.data(), w5.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db5.p, b5.data(), b5.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.wpk_bf6 = dw5.p; L.bias_bf6 = db5.p;
+    }
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
         wino2s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
@@ -1363,7 +1391,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(dws2.p, wps.data(), wps.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_split2 = dws2.p;
     }
-    if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
+    if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
+    else if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));
     else if (wino == 5) HIPCHK(launch_conv3x3_c16s2(L, c->stream));

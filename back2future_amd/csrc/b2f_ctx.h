@@ -40,6 +40,7 @@ struct PackedConv {
     // ... and the weights split into three bf16 terms for the kernel on the bf16 matrix pipe (b2f_wino4s.hip); 0 = none
     size_t w_off3 = 0;
     size_t w_off4 = 0;             // F(2x2) split packing (b2f_wino2s.hip); 0 = none
+    size_t w_off5 = 0, b_off5 = 0; // direct layers: weights pre-split for the bf16-pipe kernel (b2f_convb.hip) + bias padded to 64; 0 = none
 };
 
 struct ProfEvent {
@@ -231,6 +232,9 @@ struct b2f_ctx {
     int profile_layers = 0;        // one profile row per (layer shape, map size)
     int bf16_direct = 2;           // the 16-channel layers of the head on the bf16 matrix pipe with exactly split fp32 operands: 0 = fp32-MFMA kernels,
                                    // 1 = the 16 -> 16 layer alone (b2f_conv16b.hip), 2 = 16 -> 16 + 16 -> 32 stride 2 fused, the map between them in LDS (b2f_head.hip)
+    int bf16_conv_min_pixels = 65536;   // bf16_conv = 2: 32-output stride-1 layers on maps of at least this many pixels leave the F(4x4) kernel
+    int bf16_conv = 1;             // 1 (default): the direct (stride-2) layers on the bf16 matrix pipe with split fp32 operands (b2f_convb.hip);
+                                   // 2: also the 32-output stride-1 layers of large maps (measured slower than their F(4x4) kernel); 0: fp32-MFMA kernel
     int wino2_split = 0;           // F(4x4)-class layers, blocks of 64 outputs: 1 = Winograd F(2x2) on the bf16 matrix pipe with exactly split
                                    // fp32 operands (b2f_wino2s.hip) on maps of at least wino4_min_pixels pixels
     int wino4_hybrid = 0;          // F(4x4) two-N-tile blocks: this many of a wave's nine xi steps on the bf16 pipe with split operands (needs the

@@ -57,6 +57,8 @@ struct ConvLaunch {
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
     int w4_hybrid = 0;                 // F(4x4) persistent two-N-tile kernel: xi steps per wave that run on the bf16 pipe with split operands (0 = none)
     const void *wpk_split2 = nullptr;  // F(2x2) kernel on the bf16 pipe (b2f_wino2s.hip): its split weights, or null
+    const void *wpk_bf6 = nullptr;     // direct kernel on the bf16 pipe (b2f_convb.hip): weights pre-split into bf16 windows, or null
+    const float *bias_bf6 = nullptr;   // ... and its bias, padded to blocks of 64 outputs
     int bf16_direct = 0;               // direct 16-channel kernels on the bf16 pipe with split fp32 operands (b2f_conv16b.hip)
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
 };
@@ -75,6 +77,13 @@ hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s);
 hipError_t launch_conv3x3_c16b(const ConvLaunch &p, hipStream_t s);   // the same layer on the bf16 pipe (ConvLaunch::bf16_direct)
 size_t c16_wpk_floats();
 void c16_pack_weights(const float *w, const float *b, int Ci, const int *cin_map, float *wpk, float *bpk);
+// direct conv (stride 1 / 2) as an implicit GEMM on the bf16 pipe with split fp32 operands (b2f_convb.hip); weights
+// [n-block of 64][chunk][tap 9][k4 2][co 64] x 32 bytes
+bool convb_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_bf6(const ConvLaunch &p, hipStream_t s);
+int convb_nblk(int cout);
+size_t convb_wpk_floats(int cin_chunks, int cout);
+void convb_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // 16 -> 16 (stride 1) + 16 -> 32 (stride 2), both with LeakyReLU(0.2), as ONE streaming kernel on the bf16 pipe (b2f_head.hip): the
 // 16-channel map between them stays in LDS.  Weights: the c16 / c16s2 packings.
 struct HeadLaunch {

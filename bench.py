@@ -67,15 +67,15 @@ def conv_layers(H, W):
 
 
 MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2",
-              "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16"}
-BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
+              "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16", "E1": "conv3x3_s1_bf16", "E2": "conv3x3_s2_bf16"}
+BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
 
 
 def layer_kernels(model, step, torch):
     """Kernel class of every conv layer AS THE LIBRARY RAN IT: one eager pass with option profile_layers, whose rows are named
     conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
     C16 = 16 -> 16 kernel, S16 = 16 -> 32 stride-2 kernel, D1 / D2 = direct kernel stride 1 / 2, B16 = the 16 -> 16 layer on the bf16 pipe,
-    H16 = the fused head: 16 -> 16 and 16 -> 32 stride 2 in one kernel on the bf16 pipe, one row for both layers).
+    E1 / E2 = direct kernel on the bf16 pipe stride 1 / 2, H16 = the fused head: 16 -> 16 and 16 -> 32 stride 2 in one kernel on the bf16 pipe, one row for both layers).
     Returns {(cin_padded, cout, H_in, W_in): class}."""
     model.set_option("use_graph", 0)
     model.set_option("profile_layers", 1)
@@ -90,7 +90,7 @@ def layer_kernels(model, step, torch):
     import re
     out = {}
     for name, (ms, n) in rows.items():
-        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16|E1|E2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
         if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
             out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
             if m.group(1) == "H16":  # the fused head also holds the 16 -> 16 layer in front of its 16 -> 32 one

@@ -438,6 +438,31 @@ def test_conv16_on_the_bf16_pipe(hard, B, h, w):
     assert es.max() <= 1e-4 and es.max() <= 1.5 * ef.max() + 1e-6
 
 
+@pytest.mark.parametrize("B,ci,co,h,w,stride,scale", [(1, 32, 64, 16, 64, 2, 1.0), (2, 32, 64, 37, 71, 2, 1.0), (1, 64, 96, 33, 50, 2, 300.0), (3, 96, 128, 9, 130, 2, 1e-3),
+                                                      (1, 128, 192, 32, 60, 2, 1.0), (2, 40, 64, 20, 20, 2, 1.0), (1, 64, 100, 31, 33, 2, 1.0), (1, 24, 32, 40, 66, 2, 1.0),
+                                                      (1, 64, 32, 40, 66, 1, 1.0)])
+def test_direct_conv_on_the_bf16_pipe(hard, B, ci, co, h, w, stride, scale):
+    """Option bf16_conv = 1 (the default for the stride-2 layers of the pyramid, pwc.lua:60): the direct implicit-GEMM kernel with split
+    fp32 operands on the bf16 matrix pipe (b2f_convb.hip) against an fp64 convolution and the fp32-MFMA direct kernel: fp32-level
+    accuracy (inside test_conv3x3's bars, within 1.5x of the fp32 kernel's own error); whole blocks of 64 outputs + a 32-output
+    remainder launch, odd sizes, borders, two output tiles per wave."""
+    import torch
+    r = _rng(ci * 13 + co + h)
+    x = (r.standard_normal((B, ci, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = (r.standard_normal(co, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1, stride=stride)
+    exp = torch.where(y > 0, y, 0.2 * y).numpy()
+    with hard.options(bf16_conv=0):
+        f32 = ops.conv3x3(hard, x, wt, b, stride, True)
+    with hard.options(bf16_conv=2, bf16_conv_min_pixels=0):
+        got = ops.conv3x3(hard, x, wt, b, stride, True)
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert np.isfinite(got).all() and not np.array_equal(got, f32)
+    assert es.max() <= 1e-4 * scale and es.mean() < 5e-6 * scale
+    assert es.max() <= 1.5 * ef.max() + 1e-6 * scale
+
+
 def test_compute_flow_head_kernels_agree(hard):
     """The whole graph with the head of the pyramid on the fp32-MFMA kernels (bf16_direct = 0), with the 16 -> 16 layer on the bf16 pipe
     (1) and with the fused head (2, the default): the same function within fp32 rounding, each inside the end-to-end bar."""
