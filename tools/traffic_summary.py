@@ -37,7 +37,7 @@ def main():
            "correction": "FETCH_SIZE x 2 (gfx950: 128-B requests tallied as 64 B), KiB -> bytes; WRITE_SIZE as is"}
     fetch = last_forward(per_dispatch(base + "/FETCH_SIZE/b2f_counter_collection.csv", "FETCH_SIZE"))
     write = last_forward(per_dispatch(base + "/WRITE_SIZE/b2f_counter_collection.csv", "WRITE_SIZE"))
-    for cls, pred in (("conv", lambda n: "conv3x3" in n or "conv_first" in n or "conv_narrow" in n),
+    for cls, pred in (("conv", lambda n: "conv3x3" in n or "conv_first" in n or "conv_narrow" in n or "conv_head16" in n),
                       ("conv3x3_wino4", lambda n: "conv3x3_wino4" in n),
                       ("warp_costvol", lambda n: "warp_costvol" in n)):
         fb = sum(v for n, v in fetch if pred(n)) * 1024 * 2
