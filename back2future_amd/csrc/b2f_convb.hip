@@ -61,6 +61,9 @@ __device__ __forceinline__ void convb_split(const f32x4 v, u32x4 &wa, u32x4 &wb)
     wb = u32x4{h01, h23, convb_pk(l0, l1), convb_pk(l2, l3)};
 }
 
+#ifndef B2F_CONVB_ABLATE
+#define B2F_CONVB_ABLATE 0   // profiling only (wrong results): 1 no patch loads, 2 no weight loads, 4 no MFMAs, 8 no split / LDS writes
+#endif
 #define CONVB_MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
 
 template <int S, int NT>
@@ -107,8 +110,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;
         const int so = (int)((s1 ? c - p.seg[0].nchunks : c) * cstr * 4);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? a_rsrc1 : a_rsrc0, (int)(s1 ? s_off1[j] : s_off0[j]), so, 0));
+        for (int j = 0; j < NJ; ++j) {
+            if (B2F_CONVB_ABLATE & 1) raw[j] = f32x4{1.f, 2.f, 3.f, 4.f};
+            else raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? a_rsrc1 : a_rsrc0, (int)(s1 ? s_off1[j] : s_off0[j]), so, 0));
+        }
     };
 
     // ---- weights: [n-block][chunk][tap 9][k4 2][co 64] x (Wa | Wb); lane (co = 32 t + n, k4) ----
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
         const int so = (c * 9 + tap) * (2 * 64 * 32);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (B2F_CONVB_ABLATE & 2) { wa[slot][t] = u32x4{1u, 2u, 3u, (unsigned)tap}; wb[slot][t] = u32x4{4u, 5u, 6u, (unsigned)c}; continue; }
             wa[slot][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + t * 32 * 32, so, 0));
             wb[slot][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + t * 32 * 32 + 16, so, 0));
         }
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
         // ---- split the staged chunk into LDS ----
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if ((j + 1) * 256 <= G::NITEM || s_dst[j] >= 0) {
+            if (!(B2F_CONVB_ABLATE & 8) && ((j + 1) * 256 <= G::NITEM || s_dst[j] >= 0)) {
                 u32x4 a, b;
                 convb_split(raw[j], a, b);
                 L[s_dst[j]] = a;
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
+                    if (B2F_CONVB_ABLATE & 4) { acc[pt][t][0] += __builtin_bit_cast(float, wa[slot][t][0] ^ xa[pt][1] ^ wb[slot][t][2] ^ xb[pt][3]); continue; }
                     CONVB_MF(acc[pt][t], wa[slot][t], xa[pt]);
                     CONVB_MF(acc[pt][t], wb[slot][t], xa[pt]);
                     CONVB_MF(acc[pt][t], wa[slot][t], xb[pt]);
