@@ -178,7 +178,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                  : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
-        if ((p.wino == 0 || (p.wino == 4 && d.co <= 32)) && (d.co & 3) == 0) {   // direct layers (and 32-output Winograd-class ones): also packed for the kernel on the bf16 pipe
+        if ((p.wino == 0 || p.wino == 4) && (d.co & 3) == 0) {   // direct layers (and 32-output Winograd-class ones): also packed for the kernel on the bf16 pipe
             total = (total + 3) & ~(size_t)3;
             p.w_off5 = total;
             total += convb_wpk_floats(chunks, d.co);
@@ -395,7 +395,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.w4_hybrid = c->wino4_hybrid;
     L.wpk_split2 = (mode == 4 && c->wino2_split && p.w_off4) ? c->wpk_dev + p.w_off4 : nullptr;
     L.bf16_direct = c->bf16_direct;
-    const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && c->bf16_conv >= 2 && stride == 1 && H * W >= c->bf16_conv_min_pixels));
+    const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && p.cout <= 32) || c->bf16_conv >= 3)));
     if (bf6) { L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5; }
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
@@ -1375,7 +1375,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.w4_hybrid = c->wino4_hybrid;
     L.bf16_direct = c->bf16_direct;
     DevBuf dw5, db5;
-    const bool bf6_op = (Co & 3) == 0 && ((wino == 0 && c->bf16_conv) || (wino == 4 && c->bf16_conv >= 2 && stride == 1 && Co <= 32 && H * W >= c->bf16_conv_min_pixels));
+    const bool bf6_op = (Co & 3) == 0 && ((wino == 0 && c->bf16_conv) || (wino == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && Co <= 32) || c->bf16_conv >= 3)));
     if (bf6_op) {
         std::vector<float> w5(convb_wpk_floats(chunks, Co)), b5((size_t)convb_nblk(Co) * 64);
         convb_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w5.data(), b5.data());

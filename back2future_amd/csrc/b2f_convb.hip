@@ -66,13 +66,14 @@ __device__ __forceinline__ void convb_split(const f32x4 v, u32x4 &wa, u32x4 &wb)
 #endif
 #define CONVB_MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
 
-template <int S, int NT>
+template <int S, int NT, bool DB>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
 {
     using G = ConvbGeom<S>;
     constexpr int PW = G::PW, PLANE = G::PLANE, NJ = G::NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4 *L = reinterpret_cast<u32x4 *>(smem);                    // [window 2][k4 2][PLANE]
+    u32x4 *L = reinterpret_cast<u32x4 *>(smem);                    // [buffer 1 | 2][window 2][k4 2][PLANE]
+    constexpr int BUF = 4 * PLANE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, k4 = lane >> 5;
@@ -142,20 +143,72 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
     // window a of (patch row (2 wave + pt) S, patch column n S): + ky PW rows, + colslot(kx) columns
     const u32x4 *x_base = L + k4 * PLANE + (2 * wave * S) * PW + (S == 1 ? n : n);
 
-    request(0);
-    load_w(0, 0, 0);
-    load_w(1, 0, 1);
-    for (int c = 0; c < nchunks; ++c) {
-        // ---- split the staged chunk into LDS ----
+    auto split_to_lds = [&](u32x4 *dst) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (!(B2F_CONVB_ABLATE & 8) && ((j + 1) * 256 <= G::NITEM || s_dst[j] >= 0)) {
                 u32x4 a, b;
                 convb_split(raw[j], a, b);
-                L[s_dst[j]] = a;
-                L[2 * PLANE + s_dst[j]] = b;
+                dst[s_dst[j]] = a;
+                dst[2 * PLANE + s_dst[j]] = b;
             }
         }
+    };
+    auto mfmas = [&](const int slot, const u32x4 (&xa)[2], const u32x4 (&xb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (B2F_CONVB_ABLATE & 4) { acc[pt][t][0] += __builtin_bit_cast(float, wa[slot][t][0] ^ xa[pt][1] ^ wb[slot][t][2] ^ xb[pt][3]); continue; }
+                CONVB_MF(acc[pt][t], wa[slot][t], xa[pt]);
+                CONVB_MF(acc[pt][t], wb[slot][t], xa[pt]);
+                CONVB_MF(acc[pt][t], wa[slot][t], xb[pt]);
+            }
+    };
+    request(0);
+    load_w(0, 0, 0);
+    load_w(1, 0, 1);
+    if (DB) {
+        // ---- double-buffered patch, ONE barrier per chunk: chunk c + 1 is split into the other buffer between the taps of chunk c
+        // (its loads were requested a chunk earlier), the pixel windows of tap t + 1 are read before the MFMAs of tap t ----
+        split_to_lds(L);
+        if (nchunks > 1) request(1);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const u32x4 *xb0 = x_base + (c & 1) * BUF;
+            u32x4 xa[2][2], xb[2][2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const u32x4 *xp = xb0 + (pt * S) * PW;
+                xa[0][pt] = xp[0];
+                xb[0][pt] = xp[2 * PLANE];
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                {
+                    const int tn = tap + 2;
+                    if (tn < 9) load_w(tn % 3, c, tn);
+                    else if (c + 1 < nchunks) load_w(tn % 3, c + 1, tn - 9);
+                }
+                if (tap < 8) {
+                    const int ky = (tap + 1) / 3, kx = (tap + 1) - 3 * ky;
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const u32x4 *xp = xb0 + (pt * S + ky) * PW + G::colslot(kx);
+                        xa[(tap + 1) & 1][pt] = xp[0];
+                        xb[(tap + 1) & 1][pt] = xp[2 * PLANE];
+                    }
+                }
+                mfmas(tap % 3, xa[tap & 1], xb[tap & 1]);
+                if (tap == 4 && c + 1 < nchunks) split_to_lds(L + ((c + 1) & 1) * BUF);
+                if (tap == 5 && c + 2 < nchunks) request(c + 2);
+            }
+            __syncthreads();               // buffer (c + 1) & 1 is complete; everyone is done reading buffer c & 1
+        }
+    } else {
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- split the staged chunk into LDS ----
+        split_to_lds(L);
         __syncthreads();
         if (c + 1 < nchunks) request(c + 1);                        // lands under the MFMAs below
 #pragma unroll
@@ -167,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
                 else if (c + 1 < nchunks) load_w(tn % 3, c + 1, tn - 9);
             }
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int slot = tap % 3;
             u32x4 xa[2], xb[2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
@@ -175,17 +227,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf6(const ConvLaunch p)
                 xa[pt] = xp[0];
                 xb[pt] = xp[2 * PLANE];
             }
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (B2F_CONVB_ABLATE & 4) { acc[pt][t][0] += __builtin_bit_cast(float, wa[slot][t][0] ^ xa[pt][1] ^ wb[slot][t][2] ^ xb[pt][3]); continue; }
-                    CONVB_MF(acc[pt][t], wa[slot][t], xa[pt]);
-                    CONVB_MF(acc[pt][t], wb[slot][t], xa[pt]);
-                    CONVB_MF(acc[pt][t], wa[slot][t], xb[pt]);
-                }
+            mfmas(tap % 3, xa, xb);
         }
         __syncthreads();                                           // everyone is done reading the patch
+    }
     }
 
     // ---- epilogue: lane (pixel n, k4) holds rows (r & 3) + 8 (r >> 2) + 4 k4 of every 32-output tile: chunk j, half k4 ----
@@ -223,21 +268,21 @@ bool convb_supported(const ConvLaunch &p)
     return true;
 }
 
-template <int S, int NT>
+template <int S, int NT, bool DB>
 static hipError_t convb_launch_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
 {
     using G = ConvbGeom<S>;
     static bool attr_done_dev[64] = {false};
     bool &attr_done = attr_done_dev[attr_slot()];
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_bf6<S, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_bf6<S, NT, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (DB ? 2 : 1) * G::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int tiles = ((p.Wo + G::TW - 1) / G::TW) * ((p.Ho + G::TH - 1) / G::TH);
     ConvLaunch q = p;
     q.nb0 = nb0;
-    hipLaunchKernelGGL((conv3x3_bf6<S, NT>), dim3((unsigned)(tiles * p.nimg), (unsigned)nblk), dim3(256), G::LDS_BYTES, s, q);
+    hipLaunchKernelGGL((conv3x3_bf6<S, NT, DB>), dim3((unsigned)(tiles * p.nimg), (unsigned)nblk), dim3(256), (DB ? 2 : 1) * G::LDS_BYTES, s, q);
     return hipGetLastError();
 }
 
@@ -247,8 +292,8 @@ hipError_t launch_conv3x3_bf6(const ConvLaunch &p, hipStream_t s)
     // whole blocks of 64 outputs on the two-tile kernel; a remainder of at most 32 outputs on the one-tile kernel (first half of its block)
     const int rem = p.cout % 64, full = p.cout / 64 + (rem > 32 ? 1 : 0);
     hipError_t e = hipSuccess;
-    if (full > 0) e = p.stride == 1 ? convb_launch_t<1, 2>(p, 0, full, s) : convb_launch_t<2, 2>(p, 0, full, s);
-    if (e == hipSuccess && rem > 0 && rem <= 32) e = p.stride == 1 ? convb_launch_t<1, 1>(p, full, 1, s) : convb_launch_t<2, 1>(p, full, 1, s);
+    if (full > 0) e = p.stride == 1 ? convb_launch_t<1, 2, true>(p, 0, full, s) : convb_launch_t<2, 2, false>(p, 0, full, s);
+    if (e == hipSuccess && rem > 0 && rem <= 32) e = p.stride == 1 ? convb_launch_t<1, 1, true>(p, full, 1, s) : convb_launch_t<2, 1, false>(p, full, 1, s);
     return e;
 }
 

@@ -234,7 +234,8 @@ struct b2f_ctx {
                                    // 1 = the 16 -> 16 layer alone (b2f_conv16b.hip), 2 = 16 -> 16 + 16 -> 32 stride 2 fused, the map between them in LDS (b2f_head.hip)
     int bf16_conv_min_pixels = 65536;   // bf16_conv = 2: 32-output stride-1 layers on maps of at least this many pixels leave the F(4x4) kernel
     int bf16_conv = 1;             // 1 (default): the direct (stride-2) layers on the bf16 matrix pipe with split fp32 operands (b2f_convb.hip);
-                                   // 2: also the 32-output stride-1 layers of large maps (measured slower than their F(4x4) kernel); 0: fp32-MFMA kernel
+                                   // 2: also the 32-output stride-1 layers of large maps, 3: every F(4x4)-class layer of large maps (experiments: measured
+                                   // slower than the F(4x4) kernel, profiles/r04_bf16_direct_notes.txt (4)); 0: fp32-MFMA kernel
     int wino2_split = 0;           // F(4x4)-class layers, blocks of 64 outputs: 1 = Winograd F(2x2) on the bf16 matrix pipe with exactly split
                                    // fp32 operands (b2f_wino2s.hip) on maps of at least wino4_min_pixels pixels
     int wino4_hybrid = 0;          // F(4x4) two-N-tile blocks: this many of a wave's nine xi steps on the bf16 pipe with split operands (needs the
