@@ -185,6 +185,13 @@ int pack_all(b2f_ctx *c, const float *flat)
             p.b_off5 = total;
             total += (size_t)convb_nblk(d.co) * 64;
         }
+        if (p.wino == 4 && c->wino1d) {   // only while the option reads it (as the other optional packings)
+            total = (total + 3) & ~(size_t)3;
+            p.w_off6 = total;
+            total += w1b_wpk_floats(chunks, d.co);
+            p.b_off6 = total;
+            total += (size_t)w1b_nblk(d.co) * 64;
+        }
         if (p.wino == 4) {
             wino_choose_tiles(d.co, &p.nt2, &p.nblk2);
             p.w_off2 = total;
@@ -226,6 +233,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             if (p.w_off5) convb_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off5, host.data() + p.b_off5);
             if (p.w_off4) wino2s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off4);
             if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
+            if (p.w_off6) w1b_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off6, host.data() + p.b_off6);
         } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
                                  host.data() + p.b_off);
@@ -397,17 +405,24 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.bf16_direct = c->bf16_direct;
     const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && p.cout <= 32) || c->bf16_conv >= 3)));
     if (bf6) { L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5; }
+    bool w1d = !bf6 && mode == 4 && stride == 1 && c->wino1d && p.w_off6;
+    if (w1d) {
+        L.wpk_w1b = c->wpk_dev + p.w_off6; L.bias_w1b = c->wpk_dev + p.b_off6;
+        L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
+        w1d = w1b_supported(L);
+    }
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
+        snprintf(name, sizeof name, bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
     if (bf6 && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, s));
+    else if (w1d) HIPCHK(launch_conv3x3_w1b(L, s));
     else if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
     else if (mode == 3) HIPCHK(launch_conv3x3_c16(L, s));
@@ -789,6 +804,9 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->corr_ablate = (int)env_int("B2F_CORR_ABLATE", c->corr_ablate);
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
+        c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
+        c->w1b_stagger = (int)env_int("B2F_W1B_STAGGER", c->w1b_stagger);
+        c->w1b_store_aux = (int)env_int("B2F_W1B_STORE_AUX", c->w1b_store_aux);
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
         c->wino2_split = (int)env_int("B2F_WINO2_SPLIT", c->wino2_split);
@@ -906,6 +924,14 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "bf16_direct")) c->bf16_direct = value;
     else if (!strcmp(key, "bf16_conv")) c->bf16_conv = value;
     else if (!strcmp(key, "bf16_conv_min_pixels")) c->bf16_conv_min_pixels = value;
+    else if (!strcmp(key, "wino1d")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        const bool had = c->wino1d != 0;
+        c->wino1d = value;
+        if (had != (value != 0)) CHK(b2f_commit_weights(c));   // the packing exists only while the option reads it
+    }
     else if (!strcmp(key, "wino2_split")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -927,6 +953,12 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
         (key[0] == 's' ? c->s2_tiles_per_block : c->wino4_persistent) = value;
+    }
+    else if (!strcmp(key, "w1b_stagger") || !strcmp(key, "w1b_store_aux")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        (key[6] == 'a' ? c->w1b_stagger : c->w1b_store_aux) = value;
     }
     else if (!strcmp(key, "wino_split_pixels")) {
         HIPCHK(hipSetDevice(c->device));
@@ -966,6 +998,9 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "profile_layers") *value = c->profile_layers;
     else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
+    else if (k == "wino1d") *value = c->wino1d;
+    else if (k == "w1b_stagger") *value = c->w1b_stagger;
+    else if (k == "w1b_store_aux") *value = c->w1b_store_aux;
     else if (k == "wino4_split") *value = c->wino4_split;
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino2_split") *value = c->wino2_split;
@@ -1384,6 +1419,18 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(db5.p, b5.data(), b5.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_bf6 = dw5.p; L.bias_bf6 = db5.p;
     }
+    DevBuf dw6, db6;
+    bool w1d_op = false;
+    if (wino == 4 && stride == 1 && c->wino1d && !bf6_op) {
+        std::vector<float> w6(w1b_wpk_floats(chunks, Co)), b6((size_t)w1b_nblk(Co) * 64);
+        w1b_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w6.data(), b6.data());
+        CHK(dw6.alloc(w6.size())); CHK(db6.alloc(b6.size()));
+        HIPCHK(hipMemcpy(dw6.p, w6.data(), w6.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db6.p, b6.data(), b6.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.wpk_w1b = dw6.p; L.bias_w1b = db6.p;
+        L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
+        w1d_op = w1b_supported(L);
+    }
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
         wino2s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
@@ -1392,6 +1439,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         L.wpk_split2 = dws2.p;
     }
     if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
+    else if (w1d_op) HIPCHK(launch_conv3x3_w1b(L, c->stream));
     else if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

@@ -61,6 +61,10 @@ struct ConvLaunch {
     const float *bias_bf6 = nullptr;   // ... and its bias, padded to blocks of 64 outputs
     int bf16_direct = 0;               // direct 16-channel kernels on the bf16 pipe with split fp32 operands (b2f_conv16b.hip)
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
+    const void *wpk_w1b = nullptr;     // 1-D Winograd F(4,3) kernel on the bf16 pipe (b2f_w1b.hip): its split weights, or null
+    const float *bias_w1b = nullptr;   // ... and its bias, padded to blocks of 64 outputs
+    int w1b_stagger = 0;               // ... its blocks start (block index % 16) x this many x 64 cycles apart (tile epilogues of the CUs then do not coincide)
+    int w1b_store_aux = 0;                  // ... s_setprio of its consumer waves (0..3)
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
 // floats needed for the packed weights of a conv with `cin_chunks` K-chunks
@@ -84,6 +88,13 @@ hipError_t launch_conv3x3_bf6(const ConvLaunch &p, hipStream_t s);
 int convb_nblk(int cout);
 size_t convb_wpk_floats(int cin_chunks, int cout);
 void convb_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
+// stride-1 layers as a one-dimensional Winograd F(4,3) along x on the bf16 pipe with split fp32 operands, loader / consumer
+// persistent blocks (b2f_w1b.hip); weights [n-block of 64][chunk][step 18][window 2][N tile 2][kh 2][co 32] x 16 bytes
+bool w1b_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_w1b(const ConvLaunch &p, hipStream_t s);
+int w1b_nblk(int cout);
+size_t w1b_wpk_floats(int cin_chunks, int cout);
+void w1b_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // 16 -> 16 (stride 1) + 16 -> 32 (stride 2), both with LeakyReLU(0.2), as ONE streaming kernel on the bf16 pipe (b2f_head.hip): the
 // 16-channel map between them stays in LDS.  Weights: the c16 / c16s2 packings.
 struct HeadLaunch {
