@@ -405,9 +405,13 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.bf16_direct = c->bf16_direct;
     const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && p.cout <= 32) || c->bf16_conv >= 3)));
     if (bf6) { L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5; }
-    bool w1d = !bf6 && mode == 4 && stride == 1 && c->wino1d && p.w_off6;
+    // wino1d = 1: the n-blocks with more than 32 real outputs on the 1-D Winograd bf16 kernel, a last block of <= 32 outputs on the
+    // F(4x4) single-N-tile kernel (half the bf16 kernel's MFMAs would multiply zero padding); 2: every n-block
+    const int w1d_blocks = c->wino1d >= 2 ? w1b_nblk(p.cout) : p.cout / 64 + (p.cout % 64 > 32 ? 1 : 0);
+    bool w1d = !bf6 && mode == 4 && stride == 1 && c->wino1d && p.w_off6 && w1d_blocks > 0;
     if (w1d) {
         L.wpk_w1b = c->wpk_dev + p.w_off6; L.bias_w1b = c->wpk_dev + p.b_off6;
+        L.w1b_nblk = w1d_blocks;
         L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
         w1d = w1b_supported(L);
     }
@@ -422,7 +426,10 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
     if (bf6 && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, s));
-    else if (w1d) HIPCHK(launch_conv3x3_w1b(L, s));
+    else if (w1d) {
+        HIPCHK(launch_conv3x3_w1b(L, s));
+        if (w1d_blocks < w1b_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
+    }
     else if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
     else if (mode == 3) HIPCHK(launch_conv3x3_c16(L, s));
@@ -1428,8 +1435,9 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(dw6.p, w6.data(), w6.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(db6.p, b6.data(), b6.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_w1b = dw6.p; L.bias_w1b = db6.p;
+        L.w1b_nblk = c->wino1d >= 2 ? w1b_nblk(Co) : Co / 64 + (Co % 64 > 32 ? 1 : 0);
         L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
-        w1d_op = w1b_supported(L);
+        w1d_op = w1b_supported(L) && L.w1b_nblk > 0;
     }
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
@@ -1439,7 +1447,10 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         L.wpk_split2 = dws2.p;
     }
     if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
-    else if (w1d_op) HIPCHK(launch_conv3x3_w1b(L, c->stream));
+    else if (w1d_op) {
+        HIPCHK(launch_conv3x3_w1b(L, c->stream));
+        if (L.w1b_nblk < w1b_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));
+    }
     else if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

@@ -243,7 +243,7 @@ struct b2f_ctx {
                                    // split packing: setting it > 0 packs it); 0 = all on the fp32 MFMA
     int wino4_split = 0;           // F(4x4) layers with two full N tiles per block: 1 = on the bf16 matrix pipe with exactly split fp32 operands
                                    // (b2f_wino4s.hip; fp32-level accuracy, measured no faster: profiles/r04_wino4s_notes.txt), 0 = on the fp32 MFMA
-    int wino1d = 1;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 (default) = one-dimensional
+    int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
                                    // Winograd F(4,3) on the bf16 matrix pipe with exactly split fp32 operands, loader / consumer persistent blocks
                                    // (b2f_w1b.hip); 0 = the fp32-MFMA F(4x4) kernel of rounds 1-4 (b2f_wino4.hip)
     int w1b_stagger = 0, w1b_store_aux = 0;   // b2f_w1b.hip tuning (ConvLaunch::w1b_stagger, w1b_store_aux)

@@ -63,6 +63,7 @@ struct ConvLaunch {
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
     const void *wpk_w1b = nullptr;     // 1-D Winograd F(4,3) kernel on the bf16 pipe (b2f_w1b.hip): its split weights, or null
     const float *bias_w1b = nullptr;   // ... and its bias, padded to blocks of 64 outputs
+    int w1b_nblk = 0;                  // ... n-blocks of 64 outputs it computes (the first ones; 0 = all)
     int w1b_stagger = 0;               // ... its blocks start (block index % 16) x this many x 64 cycles apart (tile epilogues of the CUs then do not coincide)
     int w1b_store_aux = 0;                  // ... s_setprio of its consumer waves (0..3)
 };
@@ -129,6 +130,7 @@ size_t wino_wpk_floats(int cin_chunks, int nt, int nblk);
 // ---- Winograd F(4x4,3x3) variant for the wide stride-1 layers (b2f_wino4.hip): 64 output channels per
 // n-block, weights packed by wino4_pack_weights ([nblk][chunk][xi 36][k4 2][64][4])
 hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s);
+hipError_t launch_conv3x3_wino4_rem(const ConvLaunch &p, hipStream_t s);   // its last, half-empty n-block only
 // the same layers on the bf16 matrix pipe with exactly split fp32 operands (b2f_wino4s.hip): n-blocks [nb0, nb0 + nblk) of
 // 64 outputs each, persistent blocks; weights packed by wino4s_pack_weights
 bool wino4s_supported(const ConvLaunch &p);

@@ -57,14 +57,17 @@ constexpr int PR = TH + 2;                       // patch rows
 constexpr int VPLANE = PR * 8;                   // u32x4 slots of one (xi, window, kh) plane: [row 18][t 8]
 constexpr int VBUF = 6 * 2 * 2 * VPLANE;         // 3 456 slots = 55 296 bytes per chunk
 constexpr int RAWBUF = 20 * 64;                  // u32x4 slots of one raw-patch buffer: 18 rows x 34 columns x (kh 2) = 1 224, in 20 DMA pieces
-constexpr int XCH = 4 * 128;                     // u32x4 slots of the consumers' output exchange areas (2 KB per wave: two rows of a pixel tile)
+constexpr int XCH = 4 * 128;                     // u32x4 slots of the consumers' output exchange areas (2 KB per wave: one pixel pair of a pixel tile)
 constexpr int LDS_BYTES = (2 * VBUF + 2 * RAWBUF + XCH) * 16;   // 110 592 + 40 960 + 8 192 = 159 744 of the 163 840
 constexpr int NSTEP = 18;                        // (xi, ky)
 constexpr int WSTEP = 2 * 2 * 2 * 32 * 16;       // bytes of one step: [window 2][N tile 2][kh 2][co 32] x 16
 constexpr int WCHUNK = NSTEP * WSTEP;            // 73 728 bytes per (n-block, chunk)
 
+#ifndef W1B_RING
+#define W1B_RING 3     // slots of the weight ring (a divisor of 18); requested W1B_RING - 1 steps ahead
+#endif
 #ifndef B2F_W1B_ABLATE
-#define B2F_W1B_ABLATE 0   // profiling only (wrong results): 1 no raw loads, 2 no weight loads, 4 no MFMAs, 8 no transform / split, 16 no V writes, 32 no pixel-window reads, 64 no epilogue stores
+#define B2F_W1B_ABLATE 0   // profiling only (wrong results): 1 no raw loads, 2 no weight loads, 4 no MFMAs, 8 no transform / split, 16 no V writes, 32 no pixel-window reads, 64 no epilogue stores, 128 one weight load per step instead of two, 256 every tile reads the patch of tile 0 (raw loads hit L2)
 #endif
 
 __device__ __forceinline__ unsigned pk(float a, float b)
@@ -94,14 +97,14 @@ __device__ __forceinline__ void split(const f32x4 v, u32x4 &wa, u32x4 &wb)
 #if B2F_W1B_TRACE
 #define W1B_STAMP(role_, v_, i_)                                                                                              \
     do {                                                                                                                      \
-        if (p.trace && blockIdx.x == 8 && (v_) < 64) {                                                                        \
+        if (p.trace && blockIdx.x == 8 && (v_) < 64 && (B2F_W1B_TRACE == 1 || ((role_) == 0 && (i_) == 0))) {                                                                        \
             const long long t__ = (long long)__builtin_amdgcn_s_memtime();                                                    \
             if (lane == 0) p.trace[(((role_) * 64 + (v_)) * 5 + (i_))] = t__;                                                 \
         }                                                                                                                     \
     } while (0)
 #define W1B_ESTAMP(k_, i_)                                                                                                    \
     do {                                                                                                                      \
-        if (p.trace && blockIdx.x == 8 && wave == 0 && (k_) < 4) {                                                            \
+        if (p.trace && blockIdx.x == 8 && wave == 0 && (k_) < 4 && B2F_W1B_TRACE == 1) {                                      \
             const long long t__ = (long long)__builtin_amdgcn_s_memtime();                                                    \
             if (lane == 0) p.trace[5 * 64 * 5 + 2 + (k_) * 8 + (i_)] = t__;                                                   \
         }                                                                                                                     \
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
         i32x4 rs0, rs1;
         int pk_item = -1;                                           // item the offsets belong to
         auto setup_item = [&](const int k) {
-            const Item it = decode(k);
+            Item it = decode(k);
+            if (B2F_W1B_ABLATE & 256) { it.img = 0; it.ox0 = 0; it.oy0 = 0; }   // every tile reads the same patch: the raw loads hit L2
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const int i = 64 * (pw + 4 * q) + lane;
@@ -200,11 +204,14 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
             const int so = __builtin_amdgcn_readfirstlane((int)((s1 ? lc - p.seg[0].nchunks : lc) * cstr * 4));
             const i32x4 rsel = s1 ? rs1 : rs0;
             const i32x4 rs = {__builtin_amdgcn_readfirstlane(rsel[0]), __builtin_amdgcn_readfirstlane(rsel[1]), __builtin_amdgcn_readfirstlane(rsel[2]), __builtin_amdgcn_readfirstlane(rsel[3])};
+            const bool dma_nt = (p.w1b_store_aux & 4) != 0;
 #pragma unroll
             for (int q = 0; q < 5; ++q)
-                if (!(B2F_W1B_ABLATE & 1))
-                    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                                 :: "v"(doff[q]), "s"(rs), "s"(__builtin_amdgcn_readfirstlane((int)(raw_lds + (unsigned)(((v & 1) * RAWBUF + 64 * (pw + 4 * q)) * 16)))), "s"(so) : "memory");
+                if (!(B2F_W1B_ABLATE & 1)) {
+                    const int ldst = __builtin_amdgcn_readfirstlane((int)(raw_lds + (unsigned)(((v & 1) * RAWBUF + 64 * (pw + 4 * q)) * 16)));
+                    if (dma_nt) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen nt lds" :: "v"(doff[q]), "s"(rs), "s"(ldst), "s"(so) : "memory");
+                    else asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(doff[q]), "s"(rs), "s"(ldst), "s"(so) : "memory");
+                }
             if (++lc == nchunks) {                                  // past the end of the stream the last chunk is requested again (harmless)
                 if (lk + 1 < nitems) { lc = 0; ++lk; } else lc = nchunks - 1;
             }
@@ -294,12 +301,16 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.wpk_w1b)), 0, 0x7fffffff, 0x00020000);
 
     f32x16 acc[2][6];
-    u32x4 wa[3], wb[3];
+    u32x4 wa[W1B_RING], wb[W1B_RING];
     u32x4 xa[2], xb[2];
     auto load_w = [&](const int slot, const int chunk_off, const int step) {
         if (B2F_W1B_ABLATE & 2) { wa[slot] = u32x4{1u, 2u, 3u, (unsigned)step}; wb[slot] = u32x4{4u, 5u, 6u, (unsigned)chunk_off}; return; }
-        wa[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, chunk_off + step * WSTEP, 0));
-        wb[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, chunk_off + step * WSTEP + 2048, 0));
+#ifndef W1B_WAUX
+#define W1B_WAUX 0      // cache policy of the weight loads: 0 default, 16 sc1 (served by L2, not allocated in L1), 2 nt, 18 sc1 nt
+#endif
+        wa[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, chunk_off + step * WSTEP, W1B_WAUX));
+        if (B2F_W1B_ABLATE & 128) { wb[slot] = wa[slot]; return; }        // one of the two weight loads only
+        wb[slot] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, chunk_off + step * WSTEP + 2048, W1B_WAUX));
     };
     auto load_x = [&](const u32x4 *xbuf, const int mt, const int step, const int win) {
         const int xi = step / 3, ky = step - 3 * xi;
@@ -311,7 +322,10 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
     Item cur = decode(0);
     Item nxt = nitems > 1 ? decode(1) : cur;
     int w_cur = (cur.nb + p.nb0) * nchunks * WCHUNK;                // byte offset of the chunk being multiplied
-    if (nstream > 0) { load_w(0, w_cur, 0); load_w(1, w_cur, 1); }
+    if (nstream > 0) {
+#pragma unroll
+        for (int s = 0; s < W1B_RING - 1; ++s) load_w(s, w_cur, s);
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -337,8 +351,8 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int xi = s / 3;
-            if (s + 2 < NSTEP) load_w((s + 2) % 3, w_cur, s + 2);
-            else load_w((s + 2) % 3, w_nxt, s + 2 - NSTEP);
+            if (s + W1B_RING - 1 < NSTEP) load_w((s + W1B_RING - 1) % W1B_RING, w_cur, s + W1B_RING - 1);
+            else load_w((s + W1B_RING - 1) % W1B_RING, w_nxt, s + W1B_RING - 1 - NSTEP);
             if (s == NSTEP - 2) {
                 if (wave == 0) W1B_STAMP(0, v, 1);
                 W1B_BARRIER();                                      // B_v: V of chunk v + 1 is complete
@@ -346,20 +360,30 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
             }
             if (s == NSTEP - 1) xnext = V + ((v + 1) & 1) * VBUF + x_lane;
             __builtin_amdgcn_sched_barrier(0);                      // the scheduler otherwise sinks every load to its first use
+            // The six MFMAs of a step alternate between the two accumulators, and every other instruction sits between MFMAs on
+            // DIFFERENT accumulators: one instruction between two dependent MFMAs costs ~43 cycles (the trace showed 40 cycles per
+            // MFMA with the pixel-window reloads between the second and third MFMA of an accumulator, whatever the loads did).
+            if (B2F_W1B_ABLATE & 4) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                if (B2F_W1B_ABLATE & 4) {
-                    acc[mt][xi][0] += __builtin_bit_cast(float, wa[s % 3][0] ^ xa[mt][1] ^ wb[s % 3][2] ^ xb[mt][3]);
-                } else {
-                    W1B_MF(acc[mt][xi], wa[s % 3], xa[mt]);
-                    W1B_MF(acc[mt][xi], wb[s % 3], xa[mt]);
-                }
+                for (int mt = 0; mt < 2; ++mt) acc[mt][xi][0] += __builtin_bit_cast(float, wa[s % W1B_RING][0] ^ xa[mt][1] ^ wb[s % W1B_RING][2] ^ xb[mt][3]);
+            } else {
+                W1B_MF(acc[0][xi], wa[s % W1B_RING], xa[0]);
+                W1B_MF(acc[1][xi], wa[s % W1B_RING], xa[1]);
+                W1B_MF(acc[0][xi], wb[s % W1B_RING], xa[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                xa[mt] = s + 1 < NSTEP ? load_x(xcur, mt, s + 1, 0) : load_x(xnext, mt, 0, 0);   // behind the MFMAs that read it: same registers
+                xa[0] = s + 1 < NSTEP ? load_x(xcur, 0, s + 1, 0) : load_x(xnext, 0, 0, 0);   // behind the MFMAs that read it: same registers
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(B2F_W1B_ABLATE & 4)) W1B_MF(acc[mt][xi], wa[s % 3], xb[mt]);
+                W1B_MF(acc[1][xi], wb[s % W1B_RING], xa[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                xb[mt] = s + 1 < NSTEP ? load_x(xcur, mt, s + 1, 1) : load_x(xnext, mt, 0, 1);
+                xa[1] = s + 1 < NSTEP ? load_x(xcur, 1, s + 1, 0) : load_x(xnext, 1, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                W1B_MF(acc[0][xi], wa[s % W1B_RING], xb[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                xb[0] = s + 1 < NSTEP ? load_x(xcur, 0, s + 1, 1) : load_x(xnext, 0, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                W1B_MF(acc[1][xi], wa[s % W1B_RING], xb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                xb[1] = s + 1 < NSTEP ? load_x(xcur, 1, s + 1, 1) : load_x(xnext, 1, 0, 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -379,73 +403,78 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
             int le = lane;
             asm volatile("" : "+v"(le));                            // recomputed here, not held in registers across the K loop
             const int e_kh = le >> 5, e_rr = (le >> 3) & 3, e_t = le & 7;
-            u32x4 *xw = V + 2 * VBUF + 2 * RAWBUF + wave * 128;     // this wave's exchange area: [row 2][slot 64]
-            const int w_rot = 2 * (e_t >> 1), w_base = (e_rr & 1) * 64 + 8 * e_t + e_kh;
-            int wsl[4];
-#pragma unroll
-            for (int px = 0; px < 4; ++px) wsl[px] = (w_base + 2 * px) ^ w_rot;          // the rotation only touches bits 1, 2
-            const int r_slot = le ^ (2 * (le >> 4));                                    // + 64 row
-            const int s_px = le >> 1, s_kh = le & 1;                // store side: column of the tile, half of the chunk
+            // Exchange area of this wave: 2 KB = [row 4][slot 32] x 16 bytes for ONE pair of the four pixels of every column tile,
+            // logical slot = (t, pixel of the pair j, kh), stored at slot ^ (t >> 2) (the eight lanes of a 16-byte write group then fall
+            // into eight different bank groups; a read lane finds its slot inside the same aligned pair).  All lanes write (two pixels
+            // each), all lanes read (rows 0, 1 then 2, 3): no exec-masked halves, no branch.
+            u32x4 *xw = V + 2 * VBUF + 2 * RAWBUF + wave * 128;
+            const int w_slot = e_rr * 32 + ((4 * e_t + e_kh) ^ (e_t >> 2));             // + 2 j (bit 1: untouched by the rotation)
+            const int r_s = le & 31, r_half = le >> 5;              // read side: logical slot, row of the pair of rows
+            const int r_slot = r_half * 32 + (r_s ^ (r_s >> 4));                        // + 64 for rows 2, 3
+            const int s_t = r_s >> 2, s_j = (r_s >> 1) & 1, s_kh = r_s & 1;
             const int cob = (cur.nb + p.nb0) * 64 + 32 * nw;
-            // store address = resource base (image) + scalar (chunk, row) + lane (first row of this wave, column, half); lanes right
-            // of the image or past the last output channel point past the resource (the store is dropped)
-            const unsigned lane_off = ((unsigned)((cur.oy0 + 8 * mw) * p.Wo + cur.ox0 + s_px) * (unsigned)p.out_pix_stride + 4u * s_kh) * 4u;
-            const bool lane_ok = cur.ox0 + s_px < p.Wo;
-            const int row_bytes = p.Wo * p.out_pix_stride * 4;
+            // store address = resource base (image) + scalar (chunk, row pair, pixel pair) + lane (row of the pair, column, half);
+            // lanes below / right of the image or past the last output channel point past the resource (the store is dropped)
+            const int oy_w = cur.oy0 + 8 * mw;
+            const unsigned lane_off = ((unsigned)((oy_w + r_half) * p.Wo + cur.ox0 + 4 * s_t + s_j) * (unsigned)p.out_pix_stride + 4u * s_kh) * 4u;
+            typedef unsigned long long u64;
+            const u64 m_px0 = __builtin_amdgcn_ballot_w64(cur.ox0 + 4 * s_t + s_j < p.Wo), m_px1 = __builtin_amdgcn_ballot_w64(cur.ox0 + 4 * s_t + s_j + 2 < p.Wo);
+            const u64 m_lo = __builtin_amdgcn_ballot_w64(r_half == 0), m_kh0 = __builtin_amdgcn_ballot_w64(s_kh == 0);
+            const int row_bytes = p.Wo * p.out_pix_stride * 4, pair_bytes = 2 * p.out_pix_stride * 4;
             const float slope = p.leaky ? 0.2f : 1.f;               // max(v, 1 v) = v
             const f32x2 slope2 = {slope, slope};
+            u32x4 rd[2][2];                                         // pipeline: the unit read while the previous one is stored
+            f32x4 o[4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int h = 0; h <= 16; ++h) {                         // half-unit h = (pixel tile mt, 8-output chunk i, pixel pair pp)
+                if (h < 16) {
+                    const int mt = h >> 3, i = (h >> 1) & 3, pp = h & 1;
+                    if (pp == 0) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias_w1b + cob + 8 * i + 4 * e_kh);   // padded to whole n-blocks
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias_w1b + cob + 8 * i + 4 * e_kh);   // padded to whole n-blocks
-                    f32x4 o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {                // two outputs at a time: packed fp32 ops (no MFMA beside them here)
-                        const int q = 4 * i + r;
-                        const f32x2 m0 = {acc[mt][0][q], acc[mt][0][q + 1]}, m1 = {acc[mt][1][q], acc[mt][1][q + 1]}, m2 = {acc[mt][2][q], acc[mt][2][q + 1]};
-                        const f32x2 m3 = {acc[mt][3][q], acc[mt][3][q + 1]}, m4 = {acc[mt][4][q], acc[mt][4][q + 1]}, m5 = {acc[mt][5][q], acc[mt][5][q + 1]};
-                        const f32x2 bb = {bias[r], bias[r + 1]};
-                        const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-                        f32x2 o0 = ((m0 + s12) + s34) + bb;
-                        f32x2 o1 = __builtin_elementwise_fma(f32x2{2.f, 2.f}, d34, d12) + bb;
-                        f32x2 o2 = __builtin_elementwise_fma(f32x2{4.f, 4.f}, s34, s12) + bb;
-                        f32x2 o3 = (__builtin_elementwise_fma(f32x2{8.f, 8.f}, d34, d12) + m5) + bb;
-                        o0 = __builtin_elementwise_max(o0, o0 * slope2);
-                        o1 = __builtin_elementwise_max(o1, o1 * slope2);
-                        o2 = __builtin_elementwise_max(o2, o2 * slope2);
-                        o3 = __builtin_elementwise_max(o3, o3 * slope2);
-                        o[0][r] = o0[0]; o[0][r + 1] = o0[1];
-                        o[1][r] = o1[0]; o[1][r + 1] = o1[1];
-                        o[2][r] = o2[0]; o[2][r + 1] = o2[1];
-                        o[3][r] = o3[0]; o[3][r + 1] = o3[1];
+                        for (int r = 0; r < 4; r += 2) {            // two outputs at a time: packed fp32 ops (no MFMA beside them here)
+                            const int q = 4 * i + r;
+                            const f32x2 m0 = {acc[mt][0][q], acc[mt][0][q + 1]}, m1 = {acc[mt][1][q], acc[mt][1][q + 1]}, m2 = {acc[mt][2][q], acc[mt][2][q + 1]};
+                            const f32x2 m3 = {acc[mt][3][q], acc[mt][3][q + 1]}, m4 = {acc[mt][4][q], acc[mt][4][q + 1]}, m5 = {acc[mt][5][q], acc[mt][5][q + 1]};
+                            const f32x2 bb = {bias[r], bias[r + 1]};
+                            const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                            f32x2 o0 = ((m0 + s12) + s34) + bb;
+                            f32x2 o1 = __builtin_elementwise_fma(f32x2{2.f, 2.f}, d34, d12) + bb;
+                            f32x2 o2 = __builtin_elementwise_fma(f32x2{4.f, 4.f}, s34, s12) + bb;
+                            f32x2 o3 = (__builtin_elementwise_fma(f32x2{8.f, 8.f}, d34, d12) + m5) + bb;
+                            o0 = __builtin_elementwise_max(o0, o0 * slope2);
+                            o1 = __builtin_elementwise_max(o1, o1 * slope2);
+                            o2 = __builtin_elementwise_max(o2, o2 * slope2);
+                            o3 = __builtin_elementwise_max(o3, o3 * slope2);
+                            o[0][r] = o0[0]; o[0][r + 1] = o0[1];
+                            o[1][r] = o1[0]; o[1][r + 1] = o1[1];
+                            o[2][r] = o2[0]; o[2][r + 1] = o2[1];
+                            o[3][r] = o3[0]; o[3][r + 1] = o3[1];
+                        }
                     }
-                    if (i == 0) W1B_ESTAMP(k, 1 + 3 * mt);
+                    xw[w_slot] = __builtin_bit_cast(u32x4, o[2 * pp]);
+                    xw[w_slot + 2] = __builtin_bit_cast(u32x4, o[2 * pp + 1]);
+                    // Other LANES wrote what this lane reads next: to the compiler a lane still holds what it loaded from the same address
+                    // one unit earlier unless told that memory changed; the hardware side needs nothing, a wave's LDS operations execute
+                    // in order (which also keeps the writes of the next unit behind these reads)
+                    asm volatile("" ::: "memory");
+                    rd[h & 1][0] = xw[r_slot];
+                    rd[h & 1][1] = xw[r_slot + 64];
+                    asm volatile("" ::: "memory");
+                }
+                if (h > 0) {                                        // stores of the previous half-unit
+                    const int g = h - 1, mt = g >> 3, i = (g >> 1) & 3, pp = g & 1;
                     const int co_s = cob + 8 * i;                   // chunk of this store (+ 4 s_kh per lane)
-                    const int v_off = (lane_ok && co_s + 4 * s_kh < p.cout) ? (int)lane_off : -16;
-                    const int s_chunk = (co_s >> 3) * (int)p.out_chunk_stride * 4;
+                    const u64 m_co = co_s + 4 < p.cout ? ~0ull : (co_s < p.cout ? m_kh0 : 0ull);
+                    const int s_chunk = (co_s >> 3) * (int)p.out_chunk_stride * 4 + pp * pair_bytes;
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {                // rows 2 hh, 2 hh + 1 of the pixel tile through the 2 KB area
-                        if ((e_rr >> 1) == hh) {
-#pragma unroll
-                            for (int px = 0; px < 4; ++px) xw[wsl[px]] = __builtin_bit_cast(u32x4, o[px]);
-                        }
-                        // Other LANES wrote what this lane reads next.  To the compiler a lane that did not store still holds the value
-                        // it loaded from the same address one unit earlier (it moved the load into the branch of the lanes that store: even
-                        // rows wrong for half the lanes); the hardware side needs nothing, a wave's LDS operations execute in order.
-                        asm volatile("" ::: "memory");
-                        if (i == 0 && hh == 0) W1B_ESTAMP(k, 2 + 3 * mt);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const u32x4 val = xw[r_slot + 64 * q];
-                            const int row = 4 * mt + 2 * hh + q;
-                            if (!(B2F_W1B_ABLATE & 64) && cur.oy0 + 8 * mw + row < p.Ho) {
-                                if (p.w1b_store_aux == 0) __builtin_amdgcn_raw_buffer_store_b128(val, o_rsrc, v_off, s_chunk + row * row_bytes, 0);
-                                else if (p.w1b_store_aux == 1) __builtin_amdgcn_raw_buffer_store_b128(val, o_rsrc, v_off, s_chunk + row * row_bytes, 2);    // nt
-                                else if (p.w1b_store_aux == 2) __builtin_amdgcn_raw_buffer_store_b128(val, o_rsrc, v_off, s_chunk + row * row_bytes, 17);   // sc0 sc1
-                                else __builtin_amdgcn_raw_buffer_store_b128(val, o_rsrc, v_off, s_chunk + row * row_bytes, 19);                               // sc0 sc1 nt
-                            }
-                        }
+                    for (int q = 0; q < 2; ++q) {
+                        const int row = 4 * mt + 2 * q;             // rows row, row + 1
+                        const u64 m_row = oy_w + row + 1 < p.Ho ? ~0ull : (oy_w + row < p.Ho ? m_lo : 0ull);
+                        const u64 m = m_co & m_row & (pp ? m_px1 : m_px0);
+                        int v_off;
+                        asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(v_off) : "v"(lane_off), "s"(m));
+                        if (!(B2F_W1B_ABLATE & 64)) __builtin_amdgcn_raw_buffer_store_b128(rd[g & 1][q], o_rsrc, v_off, s_chunk + row * row_bytes, 0);
                     }
                 }
             }
@@ -499,7 +528,7 @@ hipError_t launch_conv3x3_w1b(const ConvLaunch &p, hipStream_t s)
         attr_done = true;
     }
     ConvLaunch q = p;
-    q.nblk = w1b_nblk(p.cout);
+    q.nblk = p.w1b_nblk > 0 ? p.w1b_nblk : w1b_nblk(p.cout);
     q.nb0 = 0;
     const int total = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH) * p.nimg * q.nblk;
     const int cap = p.w4_persist > 1 ? p.w4_persist : n_cu;          // tests: exactly that many blocks
@@ -532,7 +561,12 @@ hipError_t launch_conv3x3_w1b(const ConvLaunch &p, hipStream_t s)
             fprintf(stderr, "  epilogue of tile %d (consumer wave 0): start -> (mt 0, i 0) transform done %lld -> its first LDS write done %lld ... (mt 1, i 0) transform %lld -> write %lld ... end %lld\n",
                     k, e[1] - e[0], e[2] - e[0], e[4] - e[0], e[5] - e[0], e[7] - e[0]);
         }
-        for (int v = 0; v < 48; ++v) {
+        if (B2F_W1B_TRACE == 2) {
+            fprintf(stderr, "  consumer wave 0, loop top to loop top:");
+            for (int v = 17; v < 48; ++v) fprintf(stderr, " %lld", h[(0 * 64 + v) * 5] - h[(0 * 64 + v - 1) * 5]);
+            fprintf(stderr, "\n");
+        }
+        for (int v = 0; v < 48 && B2F_W1B_TRACE == 1; ++v) {
             const long long *c = h.data() + (0 * 64 + v) * 5;
             fprintf(stderr, "  v=%2d  C: %6lld %6lld %6lld %6lld  tot %6lld |", v, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
             for (int r = 1; r <= 4; ++r) {

@@ -1534,6 +1534,15 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
     return e;
 }
 
+// only the half-empty last n-block (the last <= 32 outputs) of a layer whose full blocks of 64 run elsewhere (b2f_w1b.hip)
+hipError_t launch_conv3x3_wino4_rem(const ConvLaunch &p, hipStream_t s)
+{
+    if (!wino4_supported(p)) return hipErrorInvalidValue;
+    const int rem = p.cout % 64;
+    if (rem == 0 || rem > 32) return hipSuccess;
+    return launch_wino4_t<1>(p, p.cout / 64, 1, s);
+}
+
 int wino4_nblk(int cout) { return (cout + 63) / 64; }
 
 size_t wino4_wpk_floats(int cin_chunks, int nblk)

@@ -2,8 +2,9 @@
     python tools/layer_prof.py [key=value ...]      # options set with b2f_set_option before the profiled passes
     python tools/layer_prof.py --batch 16 --filter convD2 s2_tiles_per_block=1
 """
+import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from back2future_amd import back2future

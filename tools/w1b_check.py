@@ -26,17 +26,18 @@ for (B, ci, co, h, w, scale, blocks) in cases:
     leaky = bool(rng.integers(2))
     res = {}
     for opt in (0, 1):
-        m.set_option("wino1d", opt)
+        m.set_option("wino1d", 2 * opt if (seed & 1) else opt)     # odd seeds: every n-block on the kernel, even ones: last <= 32 outputs on F(4x4)
         m.set_option("wino4_persistent", blocks)
         res[opt] = ops.conv3x3(m, x, wt, b, 1, leaky)
     m.set_option("wino4_persistent", 1)
     full = ops.conv3x3(m, x, wt, b, 1, leaky)
+    m.set_option("wino1d", 0)
     y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
     e = (torch.where(y > 0, y, 0.2 * y) if leaky else y).numpy()
     errs = [np.abs(res[o] - e).max() / scale for o in (0, 1)]
     mean1 = np.abs(res[1] - e).mean() / scale
     same = np.array_equal(full, res[1])      # the grid size does not change a bit
-    ok = np.isfinite(res[1]).all() and errs[1] < max(errs[0], 1e-5) and same
+    ok = np.isfinite(res[1]).all() and errs[1] <= max(errs[0], 1e-5) and same
     bad += not ok
     print("B%d %3d->%3d %3dx%3d leaky=%d scale %g blocks %d | F(4x4) fp32 max err %.2e | F(4,3) bf16x6 max %.2e mean %.2e grid-independent %s %s"
           % (B, ci, co, h, w, leaky, scale, blocks, errs[0], errs[1], mean1, same, "" if ok else "  <-- BAD"))

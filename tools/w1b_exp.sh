@@ -1,3 +1,4 @@
-for o in "w1b_store_aux=0" "w1b_store_aux=1" "w1b_store_aux=2" "w1b_store_aux=3"; do
-  echo "$o: $(python tools/layer_prof.py --filter convV1 wino1d=1 $o 2>/dev/null | grep -E 'total|200to128_256|128to128_256|96to64_256|32to32_256|128to128_128' | tr -s ' ' | tr '\n' ';')"
+for a in 0 59 2 32 25; do
+  echo "== light trace ablate=$a"
+  B2F_W1B_TRACE=16 B2F_LIB=$PWD/back2future_amd/libb2f_w1bt2a$a.so python tools/layer_prof.py --filter convV1_128to128_256 wino1d=1 2>&1 | grep -E "shader clock|convV1|loop top"
 done
