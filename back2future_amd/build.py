@@ -13,8 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libb2f.so")
 BUILD = os.path.join(HERE, "build")
-SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_w1b.hip", "b2f_wino4s.hip", "b2f_wino2s.hip", "b2f_conv16.hip", "b2f_conv16b.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
+SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_w1b.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
 HEADERS = ["b2f_internal.h", "b2f_host.h", "b2f_ctx.h", "b2f_corr5_loop.inc", os.path.join("..", "..", "include", "b2f.h")]
+# tools/experiments/csrc: kernels that were built, tested and measured no faster than the defaults; `--experiments` builds them and
+# the options that select them into libb2f_exp.so (B2F_LIB=<that file>); the product library does not contain them
+EXP_DIR = os.path.join(os.path.dirname(HERE), "tools", "experiments", "csrc")
+EXP_SOURCES = ["b2f_wino4s.hip", "b2f_wino2s.hip", "b2f_conv16b.hip"]
+EXP_OUT = os.path.join(HERE, "libb2f_exp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
@@ -31,17 +36,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(BUILD, exist_ok=True)
+def build(force=False, verbose=False, experiments=False):
+    bdir = BUILD + ("_exp" if experiments else "")
+    out = EXP_OUT if experiments else OUT
+    os.makedirs(bdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     procs = []
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
-        obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
+    srcs = [(s, os.path.join(CSRC, s)) for s in SOURCES] + ([(s, os.path.join(EXP_DIR, s)) for s in EXP_SOURCES] if experiments else [])
+    for src, sp in srcs:
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
+            cmd = [HIPCC] + FLAGS + (["-DB2F_EXPERIMENTS=1", "-I", CSRC] if experiments else []) + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -55,11 +62,11 @@ def build(force=False, verbose=False):
             print(out.decode())
     if failed:
         raise RuntimeError("libb2f build failed")
-    if force or procs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lpthread"]
+    if force or procs or _stale(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"]
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

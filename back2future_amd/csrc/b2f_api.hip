@@ -178,7 +178,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                  : conv_wpk_floats(chunks, p.nt, p.nblk);
         p.b_off = total;
         total += (size_t)p.nblk * p.nt * 32;
-        if ((p.wino == 0 || p.wino == 4) && (d.co & 3) == 0) {   // direct layers (and 32-output Winograd-class ones): also packed for the kernel on the bf16 pipe
+        if ((p.wino == 0 || (p.wino == 4 && c->bf16_conv >= 2)) && (d.co & 3) == 0) {   // direct layers: also packed for the kernel on the bf16 pipe (F(4x4)-class ones only while bf16_conv >= 2 reads that packing)
             total = (total + 3) & ~(size_t)3;
             p.w_off5 = total;
             total += convb_wpk_floats(chunks, d.co);
@@ -198,6 +198,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             total += wino_wpk_floats(chunks, p.nt2, p.nblk2);
             p.b_off2 = total;
             total += (size_t)p.nblk2 * p.nt2 * 32;
+#if B2F_EXPERIMENTS
             if (c->wino2_split) {
                 total = (total + 3) & ~(size_t)3;
                 p.w_off4 = total;
@@ -208,6 +209,7 @@ int pack_all(b2f_ctx *c, const float *flat)
                 p.w_off3 = total;
                 total += wino4s_wpk_floats(chunks, p.nblk);
             }
+#endif
         }
     }
     c->first_w_off = total; total += 27 * 16;
@@ -231,8 +233,10 @@ int pack_all(b2f_ctx *c, const float *flat)
             wino_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt2, p.nblk2,
                               host.data() + p.w_off2, host.data() + p.b_off2);
             if (p.w_off5) convb_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off5, host.data() + p.b_off5);
+#if B2F_EXPERIMENTS
             if (p.w_off4) wino2s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off4);
             if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
+#endif
             if (p.w_off6) w1b_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off6, host.data() + p.b_off6);
         } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
@@ -399,12 +403,18 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.leaky = leaky;
     L.tiles_per_block = c->s2_tiles_per_block;
     L.w4_persist = c->wino4_persistent;
+#if B2F_EXPERIMENTS
     L.wpk_split = (mode == 4 && (c->wino4_split || c->wino4_hybrid) && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
     L.w4_hybrid = c->wino4_hybrid;
     L.wpk_split2 = (mode == 4 && c->wino2_split && p.w_off4) ? c->wpk_dev + p.w_off4 : nullptr;
+#endif
     L.bf16_direct = c->bf16_direct;
-    const bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && p.cout <= 32) || c->bf16_conv >= 3)));
-    if (bf6) { L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5; }
+    bool bf6 = p.w_off5 && ((mode == 0 && c->bf16_conv) || (mode == 4 && stride == 1 && H * W >= c->bf16_conv_min_pixels && ((c->bf16_conv == 2 && p.cout <= 32) || c->bf16_conv >= 3)));
+    if (bf6) {
+        L.wpk_bf6 = c->wpk_dev + p.w_off5; L.bias_bf6 = c->wpk_dev + p.b_off5;
+        bf6 = convb_supported(L);            // the profile row below names the kernel that really runs
+        if (!bf6) { L.wpk_bf6 = nullptr; L.bias_bf6 = nullptr; }
+    }
     // wino1d = 1: the n-blocks with more than 32 real outputs on the 1-D Winograd bf16 kernel, a last block of <= 32 outputs on the
     // F(4x4) single-N-tile kernel (half the bf16 kernel's MFMAs would multiply zero padding); 2: every n-block
     const int w1d_blocks = c->wino1d >= 2 ? w1b_nblk(p.cout) : p.cout / 64 + (p.cout % 64 > 32 ? 1 : 0);
@@ -418,14 +428,14 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? (c->bf16_direct ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? ((B2F_EXPERIMENTS && c->bf16_direct) ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
         snprintf(name, sizeof name, bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
-    if (bf6 && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, s));
+    if (bf6) HIPCHK(launch_conv3x3_bf6(L, s));
     else if (w1d) {
         HIPCHK(launch_conv3x3_w1b(L, s));
         if (w1d_blocks < w1b_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
@@ -484,7 +494,10 @@ int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in
         HIPCHK(launch_pack_input((const float *)dev_in, unit, B, P.H, P.W, A + P.img, s));
     }
     // siamese feature pyramid, the three frames batched (shared weights, pwc.lua:169-211)
-    const bool head_fused = c->bf16_direct >= 2 && P.h[2] >= 4 && P.w[2] >= 4;   // level-2 conv 2 + level-3 conv 1 as one streaming kernel; cs[2] then holds the 32-channel level-3 map
+    // (the head kernel reads the c16 / c16s2 packings of its two layers: B2F_WINO=0 packs them for the direct kernel instead)
+    const int head_id1 = find_conv(c, KIND_FEAT, 2, 2), head_id2 = find_conv(c, KIND_FEAT, 3, 1);
+    const bool head_fused = c->bf16_direct >= 2 && P.h[2] >= 4 && P.w[2] >= 4 && head_id1 >= 0 && head_id2 >= 0 &&
+                            c->packed[(size_t)head_id1].wino == 3 && c->packed[(size_t)head_id2].wino == 5;   // level-2 conv 2 + level-3 conv 1 as one streaming kernel; cs[2] then holds the 32-channel level-3 map
     for (int l = 2; l <= 7; ++l) {
         const int hi = P.h[l - 1], wi = P.w[l - 1], ho = P.h[l], wo = P.w[l];
         const int Ci = (l == 2) ? kImgC : kFeat[l - 1], Co = kFeat[l];
@@ -814,9 +827,12 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
         c->w1b_stagger = (int)env_int("B2F_W1B_STAGGER", c->w1b_stagger);
         c->w1b_store_aux = (int)env_int("B2F_W1B_STORE_AUX", c->w1b_store_aux);
+#if B2F_EXPERIMENTS
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
         c->wino2_split = (int)env_int("B2F_WINO2_SPLIT", c->wino2_split);
+#endif
+        if (!use_wino()) { c->bf16_conv = 0; c->bf16_direct = 0; }   // B2F_WINO=0: every layer on the direct fp32-MFMA kernel (bit-exact fmaf chains)
         c->bf16_direct = (int)env_int("B2F_BF16_DIRECT", c->bf16_direct);
         c->bf16_conv = (int)env_int("B2F_BF16_CONV", c->bf16_conv);
         c->s2_tiles_per_block = (int)env_int("B2F_S2_TILES_PER_BLOCK", c->s2_tiles_per_block);
@@ -928,9 +944,21 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
     else if (!strcmp(key, "host_graph")) c->host_graph = value;
     else if (!strcmp(key, "profile")) c->profile = value;
     else if (!strcmp(key, "profile_layers")) c->profile_layers = value;
-    else if (!strcmp(key, "bf16_direct")) c->bf16_direct = value;
-    else if (!strcmp(key, "bf16_conv")) c->bf16_conv = value;
-    else if (!strcmp(key, "bf16_conv_min_pixels")) c->bf16_conv_min_pixels = value;
+    else if (!strcmp(key, "bf16_direct") || !strcmp(key, "bf16_conv") || !strcmp(key, "bf16_conv_min_pixels")) {
+        // a different kernel mix: captured graphs hold the old one
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        if (!strcmp(key, "bf16_direct")) {
+            if (value == 1 && !B2F_EXPERIMENTS) return fail("b2f_set_option: bf16_direct = 1 (the 16 -> 16 layer alone on the bf16 pipe) is an experiment: build with `python -m back2future_amd.build --experiments`");
+            c->bf16_direct = value;
+        } else if (!strcmp(key, "bf16_conv_min_pixels")) c->bf16_conv_min_pixels = value;
+        else {
+            const bool had = c->bf16_conv >= 2;
+            c->bf16_conv = value;
+            if (had != (value >= 2)) CHK(b2f_commit_weights(c));     // the F(4x4)-class layers carry the bf16 direct packing only while bf16_conv >= 2
+        }
+    }
     else if (!strcmp(key, "wino1d")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -939,6 +967,11 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         c->wino1d = value;
         if (had != (value != 0)) CHK(b2f_commit_weights(c));   // the packing exists only while the option reads it
     }
+#if !B2F_EXPERIMENTS
+    else if (!strcmp(key, "wino2_split") || !strcmp(key, "wino4_split") || !strcmp(key, "wino4_hybrid")) {
+        if (value != 0) return fail(std::string("b2f_set_option: ") + key + " selects an experiment kernel (tools/experiments/csrc): build with `python -m back2future_amd.build --experiments` and load libb2f_exp.so");
+    }
+#else
     else if (!strcmp(key, "wino2_split")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -955,6 +988,7 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         (key[6] == 's' ? c->wino4_split : c->wino4_hybrid) = value;
         if (had != (c->wino4_split || c->wino4_hybrid)) CHK(b2f_commit_weights(c));   // the split packing exists only while an option reads it
     }
+#endif
     else if (!strcmp(key, "s2_tiles_per_block") || !strcmp(key, "wino4_persistent")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -983,6 +1017,8 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
+        if (key[5] == 'v' && !B2F_EXPERIMENTS && (value == 2 || value == 4 || value == 6))
+            return fail("b2f_set_option: corr_variant 2 / 4 / 6 are experiment kernels: build with `python -m back2future_amd.build --experiments`");
         (key[5] == 'v' ? c->corr_variant : c->corr_ablate) = value;
     } else if (!strcmp(key, "op_wino_split")) c->op_wino_split = value;
     else if (!strcmp(key, "host_subbatch_pixels")) c->host_subbatch_pixels = value > 0 ? value : (16ll << 20);
@@ -1005,6 +1041,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "profile_layers") *value = c->profile_layers;
     else if (k == "s2_tiles_per_block") *value = c->s2_tiles_per_block;
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
+    else if (k == "experiments") *value = B2F_EXPERIMENTS;
     else if (k == "wino1d") *value = c->wino1d;
     else if (k == "w1b_stagger") *value = c->w1b_stagger;
     else if (k == "w1b_store_aux") *value = c->w1b_store_aux;
@@ -1392,12 +1429,14 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     DevBuf dpl, dx, dw, db, dy, dyp, dws, dws2;
     const size_t nx = (size_t)B * Ci * H * W, nxp = (size_t)B * H * W * Cp, ny = (size_t)B * Co * Ho * Wo;
     CHK(dpl.alloc(nx)); CHK(dx.alloc(nxp)); CHK(dw.alloc(wpk.size())); CHK(db.alloc(bpk.size())); CHK(dy.alloc(ny)); CHK(dyp.alloc(ny));
+#if B2F_EXPERIMENTS
     if (wino == 4 && (c->wino4_split || c->wino4_hybrid)) {
         std::vector<float> wps(wino4s_wpk_floats(chunks, nblk));
         wino4s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
         CHK(dws.alloc(wps.size()));
         HIPCHK(hipMemcpy(dws.p, wps.data(), wps.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+#endif
     HIPCHK(hipMemcpy(dpl.p, x, nx * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dw.p, wpk.data(), wpk.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(db.p, bpk.data(), bpk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1439,6 +1478,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
         w1d_op = w1b_supported(L) && L.w1b_nblk > 0;
     }
+#if B2F_EXPERIMENTS
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
         wino2s_pack_weights(wt, Co, Ci, nullptr, chunks, nblk, wps.data());
@@ -1446,6 +1486,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(dws2.p, wps.data(), wps.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_split2 = dws2.p;
     }
+#endif
     if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
     else if (w1d_op) {
         HIPCHK(launch_conv3x3_w1b(L, c->stream));

@@ -176,7 +176,9 @@ static hipError_t launch_persistent(K kernel, const ConvLaunch &p, int tiles_x, 
 hipError_t launch_conv3x3_c16(const ConvLaunch &p, hipStream_t s)
 {
     if (!c16_supported(p)) return hipErrorInvalidValue;
+#if B2F_EXPERIMENTS
     if (p.bf16_direct) return launch_conv3x3_c16b(p, s);
+#endif
     static bool attr_done_dev[64] = {false};
     static int n_cu_dev[64] = {0};
     const int slot = attr_slot();

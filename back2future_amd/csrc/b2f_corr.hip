@@ -551,6 +551,7 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
 // (tap coordinates, wx, wy) fit four blocks per CU (37 KB).  One direction per 128-thread block, 16 x 16 tiles, two
 // pixels per thread, the same arithmetic in the same order as the other variants: identical results.  A tile whose
 // flow spreads the taps over more than 32 x 32 pixels gathers from memory instead (block-uniform fallback).
+#if B2F_EXPERIMENTS   // variant 4 (window staged by LDS-DMA): measured slower than variant 3, profiles/r02_corr_experiments.txt (10)
 namespace v4 {
 constexpr int WP = 32, WROWS = 32;                   // window pitch / rows in pixels
 }  // namespace v4
@@ -830,6 +831,8 @@ __global__ __launch_bounds__(128, 2) void warp_costvol_win_kernel(const CorrLaun
     store_px(acc1, v1, py0 + 1);
 }
 
+#endif  // B2F_EXPERIMENTS
+
 hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
 {
     if (p_in.C % 8 != 0 || p_in.pix_stride % 4 != 0 || p_in.chunk_stride % 4 != 0 || p_in.out_pix_stride % 4 != 0 ||
@@ -860,19 +863,25 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     // default: by the map size for the small maps (so that a triplet's kernel does not depend on the batch it is computed in; the
     // instantiations are bit-identical anyway): the sixteen-wave unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet:
     // 0.043 / 0.031 ms against 0.060 / 0.081 of the block-per-tile kernels at batch 16), else by the launch size
+#if !B2F_EXPERIMENTS
+    if (p.variant == 2 || p.variant == 4 || p.variant == 6) p.variant = 3;     // experiment kernels (tools/experiments): not in this build
+#endif
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
                   : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 7 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
     if ((variant == 5 || variant == 6 || variant == 7) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
-    if (variant == 6) return launch_warp_costvol_spec(p, s);
     if (variant == 7) return launch_warp_costvol_gw(p, s);
+#if B2F_EXPERIMENTS
+    if (variant == 6) return launch_warp_costvol_spec(p, s);
     if (variant == 4) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_win_kernel<true>), dim3(2 * g2.x), dim3(128), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_win_kernel<false>), dim3(2 * g2.x), dim3(128), 0, s, p);
     } else if (variant == 2) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 2>), g2, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 2>), g2, dim3(256), 0, s, p);
-    } else if (variant == 3) {
+    } else
+#endif
+    if (variant == 3) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 1>), dim3(2 * g2.x), dim3(128), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 1>), dim3(2 * g2.x), dim3(128), 0, s, p);
     } else if (variant == 1) {

@@ -631,6 +631,7 @@ __global__ __launch_bounds__(768) C5_OCC void warp_costvol_unit_kernel(const Cor
 //                 tile-directions ahead.
 // The hardware places wave w on SIMD (w mod 4) of the block's rotation (tools/simd_probe.hip): every SIMD holds one F and one G
 // wave -- the same load on all four, and a SIMD interleaves the G wave's latency chains with its F wave's FMAs.
+#if B2F_EXPERIMENTS   // variant 6 (role-specialised form): measured slower at every level, profiles/r03_corr_unit_kernel.txt
 namespace v6 {
 constexpr int NF = 4, NG = 4;
 constexpr int NTHR = 64 * (NF + NG);            // 512
@@ -996,6 +997,8 @@ __global__ __launch_bounds__(512) void warp_costvol_spec_kernel(const CorrLaunch
 // finished tile-direction), waves 10..15 gather the taps of the NEXT stage's warped halo straight from memory (two items = 16
 // loads per thread in flight, no window), blend them into the other halo buffer, DMA the reference tile and compute the sampling
 // records a stage ahead.  128 registers per thread; one LDS-only barrier per stage.
+#endif  // B2F_EXPERIMENTS
+
 namespace v7 {
 constexpr int NF = 10, NG = 6;
 constexpr int NTHR = 64 * (NF + NG);            // 1 024
@@ -1161,6 +1164,7 @@ bool warp_costvol_unit_supported(const CorrLaunch &p)
            (double)p.h * p.w * p.out_pix_stride * 4.0 < 2147483648.0;
 }
 
+#if B2F_EXPERIMENTS
 hipError_t launch_warp_costvol_spec(const CorrLaunch &p, hipStream_t s)
 {
     using namespace v5;
@@ -1207,6 +1211,8 @@ hipError_t launch_warp_costvol_spec(const CorrLaunch &p, hipStream_t s)
 #endif
     return hipGetLastError();
 }
+
+#endif  // B2F_EXPERIMENTS
 
 hipError_t launch_warp_costvol_gw(const CorrLaunch &p, hipStream_t s)
 {

@@ -3,6 +3,12 @@
 // NHWC ("BHWD") fp32; see DESIGN.md "Data layout in HBM".
 #pragma once
 #include <hip/hip_runtime.h>
+// B2F_EXPERIMENTS=1 (python -m back2future_amd.build --experiments -> libb2f_exp.so): the kernels of tools/experiments/csrc -- forms that
+// were built, tested and measured no faster than the defaults (profiles/r04_*_notes.txt) -- and the options that select them.  The
+// product library is built without them.
+#ifndef B2F_EXPERIMENTS
+#define B2F_EXPERIMENTS 0
+#endif
 #include <cstdint>
 
 namespace b2f {

@@ -1442,6 +1442,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 pattr_done = true;
             }
             // hybrid forms (two-N-tile blocks with the split packing): p.w4_hybrid = number of bf16 steps per wave
+#if B2F_EXPERIMENTS
             if (NTV == 2 && p.wpk_split && p.w4_hybrid > 0) {
                 auto go = [&](auto kern) -> hipError_t {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES + 2304 * B2F_WINO_TRACE);
@@ -1460,6 +1461,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
                 default: return go(&conv3x3_wino4p<2, 0x1FF>);       // every step
                 }
             }
+#endif
             hipLaunchKernelGGL((conv3x3_wino4p<NTV>), dim3((unsigned)pgrid), dim3(512), P_LDS_BYTES + 2304 * B2F_WINO_TRACE, s, q);
             w4p_print_trace(do_trace_flag, trace_ptr, s);
 #if B2F_WINO_TRACE
@@ -1527,9 +1529,12 @@ hipError_t launch_conv3x3_wino4(const ConvLaunch &p, hipStream_t s)
     // n-blocks with two full N tiles: on the bf16 matrix pipe with split operands when the layer carries that packing
     // (b2f_wino4s.hip; persistent form only, K loop of at least 4 chunks), else on the fp32 MFMA
     // blocks of 64 outputs: Winograd F(2x2) on the bf16 matrix pipe with split operands when the layer carries that packing
+#if B2F_EXPERIMENTS
     if (n2 > 0 && wino2s_supported(p)) e = launch_conv3x3_wino2s(p, 0, n2, s);
     else if (n2 > 0 && p.w4_persist && p.w4_hybrid == 0 && wino4s_supported(p)) e = launch_conv3x3_wino4s(p, 0, n2, s);
-    else if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
+    else
+#endif
+    if (n2 > 0) e = launch_wino4_t<2>(p, 0, n2, s);
     if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino4_t<1>(p, nfull, 1, s);
     return e;
 }

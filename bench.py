@@ -242,14 +242,39 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # Poll every child: when one rank dies early (bad GPU, import error) the others would sit in init_process_group / a barrier
+    # until the process-group timeout; terminate them instead and report a failure.  Rank 0's stdout goes through a reader thread.
+    import threading
+    import time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(c is None for c in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+        if any(c not in (None, 0) for c in rcs):
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = b"".join(chunks)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
-    return max(abs(c) for c in rcs) and 1
+    return 1 if bad else 0
 
 
 def main():
