@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libb2f.so")
 BUILD = os.path.join(HERE, "build")
-SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_w1b.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
+SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_w1b.hip", "b2f_s2b.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
 HEADERS = ["b2f_internal.h", "b2f_host.h", "b2f_ctx.h", "b2f_corr5_loop.inc", os.path.join("..", "..", "include", "b2f.h")]
 # tools/experiments/csrc: kernels that were built, tested and measured no faster than the defaults; `--experiments` builds them and
 # the options that select them into libb2f_exp.so (B2F_LIB=<that file>); the product library does not contain them
@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # b2f_corr: the SLP vectorizer packs the 81 independent FMA chains into v_pk_fma_f32 pairs whose
 # operands are not register-adjacent, which costs ~2 v_mov per FMA; plain v_fmac is faster here.
 # b2f_wino4s: packed fp32 ops do not overlap the bf16 MFMAs (tools/mfma_bf16_chain.hip); its VALU work is written scalar on purpose.
-EXTRA = {"b2f_corr.hip": ["-fno-slp-vectorize"], "b2f_corr5.hip": ["-fno-slp-vectorize"], "b2f_wino4s.hip": ["-fno-slp-vectorize"], "b2f_wino2s.hip": ["-fno-slp-vectorize"], "b2f_conv16b.hip": ["-fno-slp-vectorize"], "b2f_head.hip": ["-fno-slp-vectorize"], "b2f_convb.hip": ["-fno-slp-vectorize"], "b2f_w1b.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"b2f_corr.hip": ["-fno-slp-vectorize"], "b2f_corr5.hip": ["-fno-slp-vectorize"], "b2f_wino4s.hip": ["-fno-slp-vectorize"], "b2f_wino2s.hip": ["-fno-slp-vectorize"], "b2f_conv16b.hip": ["-fno-slp-vectorize"], "b2f_head.hip": ["-fno-slp-vectorize"], "b2f_convb.hip": ["-fno-slp-vectorize"], "b2f_w1b.hip": ["-fno-slp-vectorize"], "b2f_s2b.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -38,7 +38,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False, experiments=False):
     bdir = BUILD + ("_exp" if experiments else "")
-    out = EXP_OUT if experiments else OUT
+    target = EXP_OUT if experiments else OUT
     os.makedirs(bdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -62,10 +62,10 @@ def build(force=False, verbose=False, experiments=False):
             print(out.decode())
     if failed:
         raise RuntimeError("libb2f build failed")
-    if force or procs or _stale(out, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"]
+    if force or procs or _stale(target, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-ldl", "-lpthread"]
         subprocess.check_call(cmd)
-    return out
+    return target
 
 
 if __name__ == "__main__":

@@ -185,6 +185,13 @@ int pack_all(b2f_ctx *c, const float *flat)
             p.b_off5 = total;
             total += (size_t)convb_nblk(d.co) * 64;
         }
+        if (p.wino == 0 && !stride1 && (d.co & 3) == 0 && d.co <= 256) {   // stride-2 layers: the loader / consumer kernel's packing
+            total = (total + 3) & ~(size_t)3;
+            p.w_off7 = total;
+            total += s2b_wpk_floats(chunks, d.co);
+            p.b_off7 = total;
+            total += (size_t)s2b_ntiles(d.co) * 32;
+        }
         if (p.wino == 4 && c->wino1d) {   // only while the option reads it (as the other optional packings)
             total = (total + 3) & ~(size_t)3;
             p.w_off6 = total;
@@ -252,6 +259,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             conv_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, p.nt, p.nblk,
                               host.data() + p.w_off, host.data() + p.b_off);
             if (p.w_off5) convb_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off5, host.data() + p.b_off5);
+            if (p.w_off7) s2b_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off7, host.data() + p.b_off7);
         }
     }
     if (c->wpk_floats != total) {
@@ -415,6 +423,14 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
         bf6 = convb_supported(L);            // the profile row below names the kernel that really runs
         if (!bf6) { L.wpk_bf6 = nullptr; L.bias_bf6 = nullptr; }
     }
+    bool s2l = false;
+    // (layers of fewer than 64 input channels keep conv3x3_bf6: with four short chunks per tile the loader / consumer block is bound by
+    // its weight traffic -- 2 KB per six MFMAs -- 32 -> 64 measured 0.45 against 0.43 ms; s2_loader = 2 sends them there too)
+    if (mode == 0 && stride == 2 && c->bf16_conv && c->s2_loader && p.w_off7 && (c->s2_loader >= 2 || p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0) >= 8)) {
+        L.wpk_s2b = c->wpk_dev + p.w_off7; L.bias_s2b = c->wpk_dev + p.b_off7;
+        s2l = s2b_supported(L);
+        if (s2l) bf6 = false;
+    }
     // wino1d = 1: the n-blocks with more than 32 real outputs on the 1-D Winograd bf16 kernel, a last block of <= 32 outputs on the
     // F(4x4) single-N-tile kernel (half the bf16 kernel's MFMAs would multiply zero padding); 2: every n-block
     const int w1d_blocks = c->wino1d >= 2 ? w1b_nblk(p.cout) : p.cout / 64 + (p.cout % 64 > 32 ? 1 : 0);
@@ -428,14 +444,15 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? ((B2F_EXPERIMENTS && c->bf16_direct) ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", s2l ? "L2" : bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? ((B2F_EXPERIMENTS && c->bf16_direct) ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
+        snprintf(name, sizeof name, s2l ? "conv3x3_s2b_%d" : bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
-    if (bf6) HIPCHK(launch_conv3x3_bf6(L, s));
+    if (s2l) HIPCHK(launch_conv3x3_s2b(L, s));
+    else if (bf6) HIPCHK(launch_conv3x3_bf6(L, s));
     else if (w1d) {
         HIPCHK(launch_conv3x3_w1b(L, s));
         if (w1d_blocks < w1b_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
@@ -825,6 +842,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
+        c->s2_loader = (int)env_int("B2F_S2_LOADER", c->s2_loader);
         c->w1b_stagger = (int)env_int("B2F_W1B_STAGGER", c->w1b_stagger);
         c->w1b_store_aux = (int)env_int("B2F_W1B_STORE_AUX", c->w1b_store_aux);
 #if B2F_EXPERIMENTS
@@ -995,6 +1013,12 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         drop_graphs(c);
         (key[0] == 's' ? c->s2_tiles_per_block : c->wino4_persistent) = value;
     }
+    else if (!strcmp(key, "s2_loader")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        c->s2_loader = value;
+    }
     else if (!strcmp(key, "w1b_stagger") || !strcmp(key, "w1b_store_aux")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -1043,6 +1067,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "experiments") *value = B2F_EXPERIMENTS;
     else if (k == "wino1d") *value = c->wino1d;
+    else if (k == "s2_loader") *value = c->s2_loader;
     else if (k == "w1b_stagger") *value = c->w1b_stagger;
     else if (k == "w1b_store_aux") *value = c->w1b_store_aux;
     else if (k == "wino4_split") *value = c->wino4_split;
@@ -1465,6 +1490,17 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(db5.p, b5.data(), b5.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_bf6 = dw5.p; L.bias_bf6 = db5.p;
     }
+    DevBuf dw7, db7;
+    bool s2l_op = false;
+    if (wino == 0 && stride == 2 && c->bf16_conv && c->s2_loader && (Co & 3) == 0 && Co <= 256 && (c->s2_loader >= 2 || chunks >= 8)) {
+        std::vector<float> w7(s2b_wpk_floats(chunks, Co)), b7((size_t)s2b_ntiles(Co) * 32);
+        s2b_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w7.data(), b7.data());
+        CHK(dw7.alloc(w7.size())); CHK(db7.alloc(b7.size()));
+        HIPCHK(hipMemcpy(dw7.p, w7.data(), w7.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db7.p, b7.data(), b7.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.wpk_s2b = dw7.p; L.bias_s2b = db7.p;
+        s2l_op = s2b_supported(L);
+    }
     DevBuf dw6, db6;
     bool w1d_op = false;
     if (wino == 4 && stride == 1 && c->wino1d && !bf6_op) {
@@ -1487,7 +1523,8 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         L.wpk_split2 = dws2.p;
     }
 #endif
-    if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
+    if (s2l_op) HIPCHK(launch_conv3x3_s2b(L, c->stream));
+    else if (bf6_op && convb_supported(L)) HIPCHK(launch_conv3x3_bf6(L, c->stream));
     else if (w1d_op) {
         HIPCHK(launch_conv3x3_w1b(L, c->stream));
         if (L.w1b_nblk < w1b_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));

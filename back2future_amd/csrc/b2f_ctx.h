@@ -41,6 +41,7 @@ struct PackedConv {
     size_t w_off3 = 0;
     size_t w_off4 = 0;             // F(2x2) split packing (b2f_wino2s.hip); 0 = none
     size_t w_off5 = 0, b_off5 = 0; // direct layers: weights pre-split for the bf16-pipe kernel (b2f_convb.hip) + bias padded to 64; 0 = none
+    size_t w_off7 = 0, b_off7 = 0; // stride-2 layers: packing of the loader / consumer kernel (b2f_s2b.hip); 0 = none
     size_t w_off6 = 0, b_off6 = 0; // F(4x4)-class layers: 1-D Winograd F(4,3) packing for the bf16-pipe loader / consumer kernel (b2f_w1b.hip); 0 = none
 };
 
@@ -246,6 +247,8 @@ struct b2f_ctx {
     int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
                                    // Winograd F(4,3) on the bf16 matrix pipe with exactly split fp32 operands, loader / consumer persistent blocks
                                    // (b2f_w1b.hip); 0 = the fp32-MFMA F(4x4) kernel of rounds 1-4 (b2f_wino4.hip)
+    int s2_loader = 1;             // stride-2 layers on the bf16 pipe (bf16_conv >= 1): 1 = those of at least 64 input channels on the loader / consumer kernel
+                                   // that computes all outputs of a tile (b2f_s2b.hip), 2 = all of them, 0 = conv3x3_bf6 (b2f_convb.hip)
     int w1b_stagger = 0, w1b_store_aux = 0;   // b2f_w1b.hip tuning (ConvLaunch::w1b_stagger, w1b_store_aux)
     int wino4_persistent = 1;      // F(4x4) kernel: 1 = persistent blocks (one per CU, K pipeline continues across tiles), 0 = one tile per block, > 1 = that many persistent blocks (tests)
     int s2_tiles_per_block = 0;    // direct stride-2 kernel: tiles chained per block (0 = launcher's rule; bit-identical either way)

@@ -69,6 +69,8 @@ struct ConvLaunch {
     const void *wpk_split = nullptr;   // F(4x4) kernel on the bf16 pipe (b2f_wino4s.hip): weights split into three bf16 terms, or null
     const void *wpk_w1b = nullptr;     // 1-D Winograd F(4,3) kernel on the bf16 pipe (b2f_w1b.hip): its split weights, or null
     const float *bias_w1b = nullptr;   // ... and its bias, padded to blocks of 64 outputs
+    const void *wpk_s2b = nullptr;     // stride-2 loader / consumer kernel on the bf16 pipe (b2f_s2b.hip): its split weights, or null
+    const float *bias_s2b = nullptr;   // ... and its bias, padded to tiles of 32 outputs
     int w1b_nblk = 0;                  // ... n-blocks of 64 outputs it computes (the first ones; 0 = all)
     int w1b_stagger = 0;               // ... its blocks start (block index % 16) x this many x 64 cycles apart (tile epilogues of the CUs then do not coincide)
     int w1b_store_aux = 0;                  // ... s_setprio of its consumer waves (0..3)
@@ -95,6 +97,13 @@ hipError_t launch_conv3x3_bf6(const ConvLaunch &p, hipStream_t s);
 int convb_nblk(int cout);
 size_t convb_wpk_floats(int cin_chunks, int cout);
 void convb_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
+// stride-2 layers as a direct implicit GEMM on the bf16 pipe with split fp32 operands in loader / consumer persistent blocks that compute all
+// outputs of a tile (b2f_s2b.hip); weights [chunk][tap 9][window 2][output tile][kh 2][co 32] x 16 bytes
+bool s2b_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_s2b(const ConvLaunch &p, hipStream_t s);
+int s2b_ntiles(int cout);
+size_t s2b_wpk_floats(int cin_chunks, int cout);
+void s2b_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // stride-1 layers as a one-dimensional Winograd F(4,3) along x on the bf16 pipe with split fp32 operands, loader / consumer
 // persistent blocks (b2f_w1b.hip); weights [n-block of 64][chunk][step 18][window 2][N tile 2][kh 2][co 32] x 16 bytes
 bool w1b_supported(const ConvLaunch &p);

@@ -67,8 +67,8 @@ def conv_layers(H, W):
 
 
 MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2",
-              "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16", "E1": "conv3x3_s1_bf16", "E2": "conv3x3_s2_bf16", "V1": "conv3x3_w1b"}
-BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16", "conv3x3_w1b")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
+              "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16", "E1": "conv3x3_s1_bf16", "E2": "conv3x3_s2_bf16", "V1": "conv3x3_w1b", "L2": "conv3x3_s2b"}
+BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16", "conv3x3_w1b", "conv3x3_s2b")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
 
 
 def layer_kernels(model, step, torch):
@@ -90,7 +90,7 @@ def layer_kernels(model, step, torch):
     import re
     out = {}
     for name, (ms, n) in rows.items():
-        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16|E1|E2|V1)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16|E1|E2|V1|L2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
         if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
             out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
             if m.group(1) == "H16":  # the fused head also holds the 16 -> 16 layer in front of its 16 -> 32 one

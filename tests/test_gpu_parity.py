@@ -1099,3 +1099,34 @@ def test_direct_kernels_everywhere_end_to_end():
     env = dict(os.environ, B2F_WINO="0", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("B,ci,co,h,w,scale,blocks", [(1, 64, 96, 16, 64, 1.0, 1), (2, 32, 64, 37, 71, 1.0, 3), (1, 64, 96, 33, 50, 300.0, 1), (3, 96, 128, 9, 130, 1e-3, 2),
+                                                      (1, 128, 192, 32, 60, 1.0, 1), (2, 40, 64, 20, 20, 1.0, 1), (1, 64, 100, 31, 33, 1.0, 7), (1, 24, 32, 40, 66, 1.0, 1),
+                                                      (1, 8, 256, 2, 2, 1.0, 1), (4, 16, 36, 1, 1, 1.0, 1), (3, 72, 160, 64, 48, 1.0, 5)])
+def test_stride2_loader_consumer_kernel(hard, B, ci, co, h, w, scale, blocks):
+    """b2f_s2b.hip (option s2_loader; 2 = every stride-2 layer, the default 1 = those of at least 64 input channels): the stride-2 convs of
+    pwc.lua:60 on the bf16 pipe with split fp32 operands in loader / consumer persistent blocks that compute all outputs of a tile.
+    Against the oracle at the direct kernels' bar, against an fp64 convolution no worse than the fp32-MFMA kernel, the same bits for
+    every number of persistent blocks -- and the same bits as conv3x3_bf6 (the same products summed in the same order)."""
+    import torch
+    r = _rng(ci * 7 + co + h)
+    x = (r.standard_normal((B, ci, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = (r.standard_normal(co, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1, stride=2)
+    exp = torch.where(y > 0, y, 0.2 * y).numpy()
+    with hard.options(bf16_conv=0):
+        f32 = ops.conv3x3(hard, x, wt, b, 2, True)
+    with hard.options(bf16_conv=1, s2_loader=0):
+        bf6 = ops.conv3x3(hard, x, wt, b, 2, True)
+    with hard.options(bf16_conv=1, s2_loader=2, wino4_persistent=blocks):
+        got = ops.conv3x3(hard, x, wt, b, 2, True)
+    with hard.options(bf16_conv=1, s2_loader=2, wino4_persistent=1):
+        got1 = ops.conv3x3(hard, x, wt, b, 2, True)
+    np.testing.assert_allclose(got, O.conv3x3(x, wt, b, 2, True), rtol=2e-5, atol=2e-5 * scale)
+    es, ef = np.abs(got - exp), np.abs(f32 - exp)
+    assert es.max() <= 1e-4 * scale and es.max() <= 1.5 * ef.max() + 1e-6 * scale
+    assert np.array_equal(got, got1)
+    if (co & 3) == 0:
+        assert np.array_equal(got, bf6)
