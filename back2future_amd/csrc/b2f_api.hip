@@ -369,7 +369,10 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     // (option adaptive_kernels); the default rule looks at the map size only: F(2x2) below wino4_min_pixels.
     bool alt = false, split = false;
     if (p.wino == 4) {
-        if (!c->adaptive_kernels) {
+        // adaptive_kernels: -1 (default) = per launch for single-triplet calls (the reference's own calling pattern, back2future.lua:73:
+        // latency matters and most launches leave the chip half empty), by map size for batches; 0 never, 1 always per launch
+        const bool per_launch = c->adaptive_kernels > 0 || (c->adaptive_kernels < 0 && c->cur_batch == 1);
+        if (!per_launch) {
             alt = H * W < c->wino4_min_pixels;
             split = alt && p.nt2 == 2 && H * W <= c->wino_split_pixels;
         } else {
@@ -502,6 +505,7 @@ struct Outs {
 // complete model:forward of models/pwc.lua.
 int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, const Plan &P, const Outs &O)
 {
+    c->cur_batch = P.B;
     float *A = c->arena;
     const int B = P.B;
     const bool full = P.full, past = c->past_flow && full;

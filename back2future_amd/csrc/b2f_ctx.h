@@ -226,7 +226,9 @@ struct b2f_ctx {
                                    // level 7 of a full-HD triplet: 64 tiles per launch at batch 16 -- 0.25 -> 0.20 ms for its six layers)
     int wino4_min_pixels = 4096;   // F(4x4) for maps of at least this many pixels, F(2x2) below: depends on the map size
                                    // only, so a triplet's result does not depend on the batch it is computed in
-    int adaptive_kernels = 0;      // 1: choose the Winograd variant per launch by block rounds on the 256 CUs (faster for
+    int cur_batch = 0;             // triplets of the forward pass being issued (run_conv's per-launch rule for single-triplet calls)
+    int adaptive_kernels = -1;     // -1 (default): per launch for single-triplet calls, by map size for batches; 0: by map size always;
+                                   // 1: choose the Winograd variant per launch by block rounds on the 256 CUs (faster for
                                    // single triplets / small batches; results then depend on the batch size at 1e-6 level)
     int corr_ablate = 0;           // profiling only, see CorrLaunch::ablate
     int corr_variant = -1;         // warp + cost volume: -1 auto, 0 regular, 1 latency variant (bit-identical results)

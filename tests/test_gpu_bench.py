@@ -36,7 +36,8 @@ def test_single_gpu_line_contract():
     # (default bf16_direct = 2: the 16 -> 16 and the 16 -> 32 stride-2 layer of the head run as ONE kernel on the bf16 pipe)
     assert layers["16to16_64x128"] == "conv_head16_bf16" and layers["32to2_32x64"] == "conv3x3_narrow2" and layers["16to32_64x128"] == "conv_head16_bf16" and layers["32to64_32x64"] == "conv3x3_s2_bf16"
     assert set(layers.values()) <= {"conv3x3_wino4", "conv3x3_wino", "conv3x3_narrow2", "conv3x3_c16", "conv3x3_s2x16", "conv3x3_s1", "conv3x3_s2",
-                                    "conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16"}
+                                    "conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16", "conv3x3_s2b", "conv3x3_w1b"}
+    assert layers["64to96_16x32"] == "conv3x3_s2b"              # stride-2 layers of >= 64 input channels: the loader / consumer kernel (default s2_loader = 1)
     assert "compute_flow_hard_exact" in d and "two_pipelines_in_flight" in d
 
 

@@ -395,7 +395,7 @@ def test_compute_flow_with_split_operand_winograd(hard):
     H, Wd = 128, 256
     ims = _triplet(r, H, Wd)
     eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
-    with hard.options(wino4_min_pixels=0, host_graph=0):
+    with hard.options(wino4_min_pixels=0, adaptive_kernels=0, host_graph=0):
         base, _, _ = hard.computeFlow(*ims)
         with hard.options(wino4_split=1):
             flow, fo, bo = hard.computeFlow(*ims)
@@ -650,15 +650,28 @@ def test_host_path_graph_replay_identical(soft):
 
 
 def test_batch_equals_single(soft):
+    """Kernel choice by map size (adaptive_kernels = 0): batching must not change a single bit.  The default (-1) picks the Winograd
+    variant per launch for SINGLE-triplet calls (latency: the reference's own calling pattern, back2future.lua:73), so a triplet computed
+    alone may differ from the same triplet inside a batch -- by fp32 rounding, far inside the 1e-3 contract; the masks may only differ
+    where est[3] is within that distance of the threshold."""
     r = _rng(9)
     trip = [_triplet(r, 64, 128) for _ in range(3)]
     im = [np.stack([t[i] for t in trip]) for i in range(3)]
+    with soft.options(adaptive_kernels=0):
+        fb, fob, bob = soft.computeFlowBatch(*im)
+        for i, t in enumerate(trip):
+            f1, fo1, bo1 = soft.computeFlow(*t)
+            np.testing.assert_array_equal(fb[i], f1)
+            np.testing.assert_array_equal(fob[i], fo1)
+            np.testing.assert_array_equal(bob[i], bo1)
+    assert soft.get_option("adaptive_kernels") == -1
     fb, fob, bob = soft.computeFlowBatch(*im)
     for i, t in enumerate(trip):
         f1, fo1, bo1 = soft.computeFlow(*t)
-        np.testing.assert_array_equal(fb[i], f1)        # batching must not change a single bit
-        np.testing.assert_array_equal(fob[i], fo1)
-        np.testing.assert_array_equal(bob[i], bo1)
+        f2, _, _ = soft.computeFlow(*t)
+        np.testing.assert_array_equal(f1, f2)           # deterministic per shape
+        assert np.abs(fb[i] - f1).max() <= 2e-5
+        assert (fob[i] != fo1).mean() <= 1e-3 and (bob[i] != bo1).mean() <= 1e-3
 
 
 def test_graph_replay_matches_eager(soft):
@@ -1045,7 +1058,7 @@ def test_compute_flow_with_the_one_dimensional_winograd_kernel(hard):
     H, Wd = 128, 256
     ims = _triplet(r, H, Wd)
     eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
-    with hard.options(wino4_min_pixels=0, host_graph=0):
+    with hard.options(wino4_min_pixels=0, adaptive_kernels=0, host_graph=0):
         base, _, _ = hard.computeFlow(*ims)
         for mode in (1, 2):
             with hard.options(wino1d=mode):
