@@ -441,7 +441,6 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     if (w1d) {
         L.wpk_w1b = c->wpk_dev + p.w_off6; L.bias_w1b = c->wpk_dev + p.b_off6;
         L.w1b_nblk = w1d_blocks;
-        L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
         w1d = w1b_supported(L);
     }
     char name[48];
@@ -847,8 +846,6 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
         c->s2_loader = (int)env_int("B2F_S2_LOADER", c->s2_loader);
-        c->w1b_stagger = (int)env_int("B2F_W1B_STAGGER", c->w1b_stagger);
-        c->w1b_store_aux = (int)env_int("B2F_W1B_STORE_AUX", c->w1b_store_aux);
 #if B2F_EXPERIMENTS
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
@@ -1023,12 +1020,6 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         drop_graphs(c);
         c->s2_loader = value;
     }
-    else if (!strcmp(key, "w1b_stagger") || !strcmp(key, "w1b_store_aux")) {
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipDeviceSynchronize());
-        drop_graphs(c);
-        (key[6] == 'a' ? c->w1b_stagger : c->w1b_store_aux) = value;
-    }
     else if (!strcmp(key, "wino_split_pixels")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
@@ -1072,8 +1063,6 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "experiments") *value = B2F_EXPERIMENTS;
     else if (k == "wino1d") *value = c->wino1d;
     else if (k == "s2_loader") *value = c->s2_loader;
-    else if (k == "w1b_stagger") *value = c->w1b_stagger;
-    else if (k == "w1b_store_aux") *value = c->w1b_store_aux;
     else if (k == "wino4_split") *value = c->wino4_split;
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino2_split") *value = c->wino2_split;
@@ -1515,7 +1504,6 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(db6.p, b6.data(), b6.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_w1b = dw6.p; L.bias_w1b = db6.p;
         L.w1b_nblk = c->wino1d >= 2 ? w1b_nblk(Co) : Co / 64 + (Co % 64 > 32 ? 1 : 0);
-        L.w1b_stagger = c->w1b_stagger; L.w1b_store_aux = c->w1b_store_aux;
         w1d_op = w1b_supported(L) && L.w1b_nblk > 0;
     }
 #if B2F_EXPERIMENTS

@@ -251,7 +251,6 @@ struct b2f_ctx {
                                    // (b2f_w1b.hip); 0 = the fp32-MFMA F(4x4) kernel of rounds 1-4 (b2f_wino4.hip)
     int s2_loader = 1;             // stride-2 layers on the bf16 pipe (bf16_conv >= 1): 1 = those of at least 64 input channels on the loader / consumer kernel
                                    // that computes all outputs of a tile (b2f_s2b.hip), 2 = all of them, 0 = conv3x3_bf6 (b2f_convb.hip)
-    int w1b_stagger = 0, w1b_store_aux = 0;   // b2f_w1b.hip tuning (ConvLaunch::w1b_stagger, w1b_store_aux)
     int wino4_persistent = 1;      // F(4x4) kernel: 1 = persistent blocks (one per CU, K pipeline continues across tiles), 0 = one tile per block, > 1 = that many persistent blocks (tests)
     int s2_tiles_per_block = 0;    // direct stride-2 kernel: tiles chained per block (0 = launcher's rule; bit-identical either way)
     long long host_subbatch_pixels = 16ll << 20;

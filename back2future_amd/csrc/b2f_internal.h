@@ -72,8 +72,6 @@ struct ConvLaunch {
     const void *wpk_s2b = nullptr;     // stride-2 loader / consumer kernel on the bf16 pipe (b2f_s2b.hip): its split weights, or null
     const float *bias_s2b = nullptr;   // ... and its bias, padded to tiles of 32 outputs
     int w1b_nblk = 0;                  // ... n-blocks of 64 outputs it computes (the first ones; 0 = all)
-    int w1b_stagger = 0;               // ... its blocks start (block index % 16) x this many x 64 cycles apart (tile epilogues of the CUs then do not coincide)
-    int w1b_store_aux = 0;                  // ... s_setprio of its consumer waves (0..3)
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
 // floats needed for the packed weights of a conv with `cin_chunks` K-chunks

@@ -149,12 +149,6 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
         return it;
     };
 
-    // tile epilogues (128 KB of stores per CU) of blocks that start together coincide for the whole launch: every CU then writes at
-    // the same time, at the HBM's pace, with its matrix pipe idle.  Start the blocks out of phase.
-    if (p.w1b_stagger > 0) {
-        const int n = ((int)blockIdx.x & 15) * p.w1b_stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);        // 64 cycles each
-    }
     if (wave >= 4) {
         // ============================================ PRODUCERS ============================================
         const int pw = wave - 4;
@@ -204,13 +198,11 @@ __global__ __launch_bounds__(512) void conv3x3_w1b(const ConvLaunch p)
             const int so = __builtin_amdgcn_readfirstlane((int)((s1 ? lc - p.seg[0].nchunks : lc) * cstr * 4));
             const i32x4 rsel = s1 ? rs1 : rs0;
             const i32x4 rs = {__builtin_amdgcn_readfirstlane(rsel[0]), __builtin_amdgcn_readfirstlane(rsel[1]), __builtin_amdgcn_readfirstlane(rsel[2]), __builtin_amdgcn_readfirstlane(rsel[3])};
-            const bool dma_nt = (p.w1b_store_aux & 4) != 0;
 #pragma unroll
             for (int q = 0; q < 5; ++q)
                 if (!(B2F_W1B_ABLATE & 1)) {
                     const int ldst = __builtin_amdgcn_readfirstlane((int)(raw_lds + (unsigned)(((v & 1) * RAWBUF + 64 * (pw + 4 * q)) * 16)));
-                    if (dma_nt) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen nt lds" :: "v"(doff[q]), "s"(rs), "s"(ldst), "s"(so) : "memory");
-                    else asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(doff[q]), "s"(rs), "s"(ldst), "s"(so) : "memory");
+                    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(doff[q]), "s"(rs), "s"(ldst), "s"(so) : "memory");
                 }
             if (++lc == nchunks) {                                  // past the end of the stream the last chunk is requested again (harmless)
                 if (lk + 1 < nitems) { lc = 0; ++lk; } else lc = nchunks - 1;
