@@ -133,7 +133,7 @@ int pack_all(b2f_ctx *c, const float *flat)
         p.cout = d.co;
         // stride-1 layers with >= 16 outputs run on the Winograd kernel (the first conv of a convUnit
         // has stride 2, the last decoder layer has 2 outputs: direct kernel)
-        const bool stride1 = !(d.kind == KIND_FEAT && d.idx == 1);
+        const bool stride1 = !(d.kind == KIND_FEAT && d.idx == 1 && d.level >= 2);   // (the level-1 unit of pwc_skip = 0 has stride 1, pwc.lua:172)
         p.wino = stride1 ? wino_mode(d.co) : 0;
         if (p.wino == 1 && d.kind != KIND_FEAT && d.idx == 1) p.wino = 0;   // two K segments: not for the narrow kernel
         if (stride1 && use_wino() && d.ci == 16 && d.co == 16) p.wino = 3;  // level-2 convUnit: dedicated kernel
@@ -185,7 +185,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             p.b_off5 = total;
             total += (size_t)convb_nblk(d.co) * 64;
         }
-        if (p.wino == 0 && !stride1 && (d.co & 3) == 0 && d.co <= 256) {   // stride-2 layers: the loader / consumer kernel's packing
+        if (p.wino == 0 && !stride1 && (d.co & 31) == 0 && d.co <= 256) {   // stride-2 layers: the loader / consumer kernel's packing
             total = (total + 3) & ~(size_t)3;
             p.w_off7 = total;
             total += s2b_wpk_floats(chunks, d.co);
@@ -222,9 +222,9 @@ int pack_all(b2f_ctx *c, const float *flat)
     c->first_w_off = total; total += 27 * 16;
     c->first_b_off = total; total += 16;
     std::vector<float> host(total, 0.f);
-    {
-        const int id = find_conv(c, KIND_FEAT, 2, 1);   // Torch 16 x 3 x 3 x 3 -> [tap (c,ky,kx)][cout]
-        const ConvDesc &d = c->lay[(size_t)id];
+    const int id_first = find_conv(c, KIND_FEAT, 2, 1);   // Torch 16 x 3 x 3 x 3 -> [tap (c,ky,kx)][cout]
+    if (id_first >= 0 && c->lay[(size_t)id_first].ci == 3 && c->lay[(size_t)id_first].co == 16) {   // (absent with pwc_siamese = 0, 16 -> 16 with pwc_skip = 0)
+        const ConvDesc &d = c->lay[(size_t)id_first];
         for (int o = 0; o < 16; ++o) {
             for (int t = 0; t < 27; ++t) host[c->first_w_off + (size_t)t * 16 + o] = flat[d.w_off + (size_t)o * 27 + t];
             host[c->first_b_off + o] = flat[d.b_off + o];

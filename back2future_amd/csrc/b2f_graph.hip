@@ -1,6 +1,9 @@
 // Generic executor for the graph shapes of createModelMulti (models/pwc.lua:87-508) other than the shipped one:
-// any odd search window (pwc_ws), 2..7 levels, pwc_skip >= 1, two_frame, pwc_sum_cvs, residual, occ_input,
-// rescale_flow, flownet_factor (createModelMulti(nil) itself is win 5 / levels 4, pwc.lua:88).
+// any odd search window (pwc_ws), 2..7 levels, pwc_skip >= 0, two_frame, pwc_sum_cvs, residual, occ_input,
+// rescale_flow, flownet_factor, pwc_siamese (createModelMulti(nil) itself is win 5 / levels 4, pwc.lua:88).
+// pwc_skip = 0 (pwc.lua:120-122,171-173,359,423-429,462-471): a stride-1 level-1 unit on the image, decoders down to full
+// resolution, the level's own flow / occlusion maps as outputs.  pwc_siamese = 0 (pwc.lua:125-127,175,182): the
+// average-pooled 3-channel image in place of the learned pyramid (8-float pixel records with five zeros = one chunk).
 // The shipped graph keeps its fused fast path (b2f_api.hip:forward_impl); here every node of the Lua graph is one or
 // a few straightforward kernels -- feature warps materialised (warpingUnit, pwc.lua:68-73), cost volumes for any
 // window, JoinTable as channel copies into a zero-padded chunk-planar decoder input -- and the convolutions run on the
@@ -189,22 +192,35 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
             GL(launch_avgpool2_nhwc(src, B, hk, wk, kImgC, ds[k] + (size_t)f * B * (hk / 2) * (wk / 2) * kImgC, s));
         }
     }
-    // siamese feature pyramid, three frames batched (pwc.lua:169-211)
+    // feature pyramid, three frames batched (pwc.lua:169-211); FS(l) = floats per pixel of a level's chunk-planar map
+    auto FS = [&](int l) { return (g.feat(l) + 7) / 8 * 8; };
     float *cs[8] = {nullptr};
-    float *tmp = A.take((size_t)3 * B * hh[2] * ww[2] * kFeat[2]);
-    for (int l = 2; l <= L; ++l) {
-        cs[l] = A.take((size_t)3 * B * hh[l] * ww[l] * kFeat[l]);
-        if (dry) continue;
-        if (l == 2) {
-            HIPCHK(launch_conv_first((const float *)dev_in, unit, B, H, W, c->wpk_dev + c->first_w_off, c->wpk_dev + c->first_b_off, tmp, s));
-        } else {
-            const ConvSeg in1 = cp8_seg(cs[l - 1], kFeat[l - 1], (size_t)hh[l - 1] * ww[l - 1]);
-            CHK(run_conv_layer(c, s, cap, find_conv_id(c, KIND_FEAT, l, 1), &in1, 3 * B, hh[l - 1], ww[l - 1], 2, 1, tmp));
+    if (!g.siamese) {   // pwc.lua:175,182: nn.Identity / nn.SpatialAveragePooling(2,2,2,2) of the image
+        cs[1] = img;
+        for (int l = 2; l <= L; ++l) {
+            cs[l] = A.take((size_t)3 * B * hh[l] * ww[l] * kImgC);
+            GL(launch_avgpool2_nhwc(cs[l - 1], 3 * B, hh[l - 1], ww[l - 1], kImgC, cs[l], s));
         }
-        const ConvSeg in2 = cp8_seg(tmp, kFeat[l], (size_t)hh[l] * ww[l]);
-        CHK(run_conv_layer(c, s, cap, find_conv_id(c, KIND_FEAT, l, 2), &in2, 3 * B, hh[l], ww[l], 1, 1, cs[l]));
+    } else {
+        const int l0 = g.feat_first();
+        float *tmp = A.take((size_t)3 * B * hh[l0] * ww[l0] * FS(l0));
+        for (int l = l0; l <= L; ++l) {
+            cs[l] = A.take((size_t)3 * B * hh[l] * ww[l] * FS(l));
+            if (dry) continue;
+            if (l == 1) {            // convUnit(3, featMaps[1], 1) on the packed frames (pwc.lua:171-173)
+                const ConvSeg in1 = cp8_seg(img, 3, (size_t)H * W);
+                CHK(run_conv_layer(c, s, cap, find_conv_id(c, KIND_FEAT, 1, 1), &in1, 3 * B, H, W, 1, 1, tmp));
+            } else if (l == 2 && l0 == 2) {
+                HIPCHK(launch_conv_first((const float *)dev_in, unit, B, H, W, c->wpk_dev + c->first_w_off, c->wpk_dev + c->first_b_off, tmp, s));
+            } else {
+                const ConvSeg in1 = cp8_seg(cs[l - 1], g.feat(l - 1), (size_t)hh[l - 1] * ww[l - 1]);
+                CHK(run_conv_layer(c, s, cap, find_conv_id(c, KIND_FEAT, l, 1), &in1, 3 * B, hh[l - 1], ww[l - 1], 2, 1, tmp));
+            }
+            const ConvSeg in2 = cp8_seg(tmp, g.feat(l), (size_t)hh[l] * ww[l]);
+            CHK(run_conv_layer(c, s, cap, find_conv_id(c, KIND_FEAT, l, 2), &in2, 3 * B, hh[l], ww[l], 1, 1, cs[l]));
+        }
     }
-    auto frame = [&](int l, int f) { return cs[l] ? cs[l] + (size_t)(f - 1) * B * hh[l] * ww[l] * kFeat[l] : nullptr; };
+    auto frame = [&](int l, int f) { return cs[l] ? cs[l] + (size_t)(f - 1) * B * hh[l] * ww[l] * FS(l) : nullptr; };
 
     float *ws[4][8] = {{nullptr}};          // warped features, chunk-planar
     float *ufs[9] = {nullptr}, *ubfs[9] = {nullptr};   // packed B x (2h x 2w) x 2, index = the level they come from
@@ -213,7 +229,7 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
     auto dec_buf = [&](size_t px, int i) { return A.take(px * kDec[i]); };
 
     for (int l = L; l >= LST; --l) {   // pwc.lua:237
-        const int h = hh[l], w = ww[l], C = kFeat[l], chunksC = C / 8;
+        const int h = hh[l], w = ww[l], C = g.feat(l), chunksC = (C + 7) / 8;
         const size_t hw = (size_t)h * w, px = (size_t)B * hw;
         const float *ref = frame(l, 2);
         const float *in_fut = (l == L) ? frame(l, 3) : ws[3][l];
@@ -262,7 +278,7 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
                 uoccs[l] = A.take(px * 4 * 2);
                 GK(softmax_nearest_kernel, dim3(nblk(px * 4)), dim3(256), 0, s, logits, B, h, w, 2, uoccs[l]);
             }
-            const int f = 1 << g.skip;
+            const int f = 1 << g.skip;   // skip_occs = skip x nearest x2; pwc_skip = 0: occs[l] itself (pwc.lua:468-470)
             float *o = dry ? nullptr : outs[(l - LST) * per + (past ? 2 : 1)];
             GK(softmax_nearest_kernel, dim3(nblk(px * f * f)), dim3(256), 0, s, logits, B, h, w, f, o);
         }
@@ -288,6 +304,11 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
         // upsampling (pwc.lua:359-390): ufs = bilinear x2 [x 2.0]; skip_ufs = l_st - 2 more of the same
         for (int pass = 0; pass < (past ? 2 : 1); ++pass) {
             float *src = pass ? bfs : fs;
+            if (g.skip == 0) {   // pwc.lua:462-466: fs[l] / bfs[l] are the outputs; ufs only feeds the next level (:359)
+                float *o = dry ? nullptr : outs[(l - LST) * per + pass];
+                GL(launch_nhwc_to_planar(src, 8, 2, B, h, w, o, s));
+                if (l == LST) continue;
+            }
             float *u = A.take(px * 4 * 2);
             GL(launch_upsample_flow2x(src, 8, B, h, w, u, s));
             if (g.rescale_flow) GK(scale_kernel, dim3(nblk(px * 8)), dim3(256), 0, s, u, px * 8, 2.0f);
@@ -300,6 +321,7 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
                 if (g.rescale_flow) GK(scale_kernel, dim3(nblk((size_t)B * ch_ * cw_ * 8)), dim3(256), 0, s, nx, (size_t)B * ch_ * cw_ * 8, 2.0f);
                 cur = nx; ch_ *= 2; cw_ *= 2;
             }
+            if (g.skip == 0) continue;
             float *o = dry ? nullptr : outs[(l - LST) * per + pass];
             GL(launch_nhwc_to_planar(cur, 2, 2, B, ch_, cw_, o, s));
         }
@@ -308,7 +330,7 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
         for (int f = 1; f <= 3; f += 2) {
             if (l > LST && f >= f_i && f <= l_i) {
                 const float k = g.rescale_flow ? (float)((double)g.flownet_factor * (f - 2)) : (float)((double)g.flownet_factor * (f - 2) / std::pow(2.0, l - 2));
-                const int Cn = kFeat[l - 1];
+                const int Cn = FS(l - 1);
                 ws[f][l - 1] = A.take(px * 4 * Cn);
                 GK(warp_cp8_kernel, dim3(nblk(px * 4 * Cn)), dim3(256), 0, s, frame(l - 1, f), Cn / 8, ufs[l], k, B, 2 * h, 2 * w, ws[f][l - 1]);
             }

@@ -22,9 +22,9 @@ std::vector<ConvDesc> weight_layout(const GraphOpts &o, long long *total)
         d.b_off = off; off += co;
         v.push_back(d);
     };
-    for (int l = 2; l <= o.levels; ++l) {   // convUnit, pwc.lua:58-65
-        add(KIND_FEAT, l, 1, kFeatH[l - 1], kFeatH[l]);
-        add(KIND_FEAT, l, 2, kFeatH[l], kFeatH[l]);
+    for (int l = o.feat_first(); o.siamese && l <= o.levels; ++l) {   // convUnit, pwc.lua:58-65,169-183
+        add(KIND_FEAT, l, 1, l == 1 ? 3 : o.feat(l - 1), o.feat(l));
+        add(KIND_FEAT, l, 2, o.feat(l), o.feat(l));
     }
     for (int l = o.levels; l >= o.l_st(); --l) {   // decoder(), pwc.lua:76-85
         const int kinds[3] = {KIND_OCC, KIND_FLOW, KIND_PAST};
@@ -88,11 +88,12 @@ bool parse_graph_opts(const char *text, GraphOpts &o, std::string &err)
         else if (k == "residual") o.residual = iv != 0;
         else if (k == "occ_input") o.occ_input = iv != 0;
         else if (k == "rescale_flow") o.rescale_flow = iv != 0;
+        else if (k == "siamese" || k == "pwc_siamese") o.siamese = iv != 0;
         else if (k == "flownet_factor") o.flownet_factor = (float)num;
         else { err = "unknown graph option '" + k + "'"; return false; }
     }
     if (!o.valid()) {
-        err = "unsupported graph options (need odd win <= 15, 2 <= levels <= 7, 1 <= skip < levels; frames = 3 and pwc_siamese = 1 are fixed)";
+        err = "unsupported graph options (need odd win <= 15, 2 <= levels <= 7, 0 <= skip < levels; frames = 3 is fixed)";
         return false;
     }
     return true;
@@ -101,8 +102,8 @@ bool parse_graph_opts(const char *text, GraphOpts &o, std::string &err)
 std::string graph_opts_string(const GraphOpts &o)
 {
     char buf[256];
-    snprintf(buf, sizeof buf, "win=%d,levels=%d,skip=%d,two_frame=%d,sum_cvs=%d,residual=%d,occ_input=%d,rescale_flow=%d,flownet_factor=%g,past_flow=%d",
-             o.win, o.levels, o.skip, o.two_frame, o.sum_cvs, o.residual, o.occ_input, o.rescale_flow, (double)o.flownet_factor, o.past_flow ? 1 : 0);
+    snprintf(buf, sizeof buf, "win=%d,levels=%d,skip=%d,two_frame=%d,sum_cvs=%d,residual=%d,occ_input=%d,rescale_flow=%d,siamese=%d,flownet_factor=%g,past_flow=%d",
+             o.win, o.levels, o.skip, o.two_frame, o.sum_cvs, o.residual, o.occ_input, o.rescale_flow, o.siamese, (double)o.flownet_factor, o.past_flow ? 1 : 0);
     return buf;
 }
 

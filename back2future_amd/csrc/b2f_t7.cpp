@@ -313,16 +313,19 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
     std::vector<Ref> nodes = array_of(field(gm, "forwardnodes"));
     if (nodes.empty()) { err = "gModule has no forwardnodes"; return false; }
 
-    static const int kLevelOfFeatIn[8] = {0, 0, 3, 16, 32, 64, 96, 128};   // nInputPlane of convUnit l
+    static const int kLevelOfFeatIn[8] = {0, 0, 3, 16, 32, 64, 96, 128};   // nInputPlane of convUnit l (pwc_skip >= 1)
     struct Dec {
         int n, kind;
+        int pos = 0;                                                      // index of the node in forwardnodes
         std::vector<ConvW> convs;
     };
     std::map<int, std::vector<ConvW>> feat;                               // level -> 2 convs
     std::vector<Dec> decs;
     std::set<const Obj *> seen_seq;
     int file_win = 0;
+    int node_pos = -1;
     for (const Ref &node : nodes) {
+        ++node_pos;
         Ref data = field(node, "data");
         Ref mod = data ? field(data, "module") : nullptr;
         if (mod && class_is(mod, "nn.CostVolMulti")) {
@@ -347,7 +350,10 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
         if (convs.size() == 2) {
             int level = 0;
             for (int l = 2; l <= 7; ++l)
-                if (convs[0].ci == kLevelOfFeatIn[l] && convs[0].co == kFeatH[l]) level = l;
+                if (convs[0].ci == kLevelOfFeatIn[l] && convs[0].co == kFeatH[l] && convs[0].stride == 2) level = l;
+            // pwc_skip = 0 (pwc.lua:120-122,171-173): convUnit(3, 16, 1) on level 1, convUnit(16, 16, 2) on level 2
+            if (convs[0].ci == 3 && convs[0].co == kFeatH[2] && convs[0].stride == 1) level = 1;
+            if (convs[0].ci == kFeatH[2] && convs[0].co == kFeatH[2] && convs[0].stride == 2) level = 2;
             if (!level) { err = "unexpected convUnit shape"; return false; }
             if (!feat.count(level)) feat[level] = std::move(convs);   // the three siamese clones share weights
         } else if (convs.size() == 6) {
@@ -362,13 +368,18 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
             if (to_softmax) d.kind = KIND_OCC;
             else d.kind = (mulconstant_signs(node, 0) & 1) ? KIND_FLOW : KIND_PAST;
             d.convs = std::move(convs);
+            d.pos = node_pos;
             decs.push_back(std::move(d));
         }
     }
+    if (feat.empty() && !decs.empty()) { err = "no convUnit in the graph: a pwc_siamese = 0 model's decoders cannot be told apart by their shapes -- not supported from .t7 (pass the flat weights to b2f_init_ex instead)"; return false; }
     if (feat.empty() || decs.empty()) { err = "no convUnit / decoder found in the graph"; return false; }
+    if (!infer && !g.siamese) { err = "pwc_siamese = 0 graphs are not supported from .t7"; return false; }
+    if (!infer && (feat.count(1) != 0) != (g.skip == 0)) { err = std::string("the file ") + (feat.count(1) ? "has" : "has no") + " level-1 convUnit, the graph options say pwc_skip = " + std::to_string(g.skip); return false; }
     if (infer) {
         g = GraphOpts();
         if (file_win) g.win = file_win;
+        if (feat.count(1)) g.skip = 0;   // featMaps[1] = 16 enters occ_in() / flow_in() of level 1 below
         g.levels = feat.rbegin()->first;
         // win / levels in range before they enter occ_in() / flow_in() (win * win) below; skip is inferred later
         if (!(g.win >= 1 && (g.win & 1) && g.win <= 15 && g.levels >= 2 && g.levels <= 7)) { err = "the file's graph shape is outside what this library runs: " + graph_opts_string(g); return false; }
@@ -378,12 +389,30 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
     }
     if (feat.rbegin()->first != g.levels) { err = "the file has " + std::to_string(feat.rbegin()->first) + " pyramid levels, the graph options say " + std::to_string(g.levels); return false; }
     // decoder level = the level whose first-layer width for that role is the decoder's (widths differ per level: pwc.lua:288-337)
+    // With pwc_skip = 0 levels 1 and 2 both carry 16 maps (pwc.lua:120-122): their decoders have the same width and are told
+    // apart by the order of the nodes -- forwardnodes is a topological order (level 2 feeds level 1) or, in files written
+    // back to front, its reverse, which the position of the coarsest level's decoder (width = the cost volume alone) shows.
     std::map<std::pair<int, int>, std::vector<ConvW>> dec;                // (level, kind) -> 6 convs
-    int lmin = 8;
+    int lmin = 8, pos_coarsest = -1, pos_other = -1;
+    for (const Dec &d : decs) {
+        if (d.kind == KIND_OCC) continue;
+        if (d.n == g.flow_in(g.levels)) pos_coarsest = d.pos;
+        else pos_other = d.pos;                                            // any finer level's flow decoder
+    }
+    const bool back_to_front = pos_coarsest >= 0 && pos_other >= 0 && pos_coarsest > pos_other;
     for (Dec &d : decs) {
         int level = 0;
-        for (int l = 2; l <= g.levels; ++l)
+        for (int l = g.feat_first(); l <= g.levels; ++l)
             if (d.n == (d.kind == KIND_OCC ? g.occ_in(l) : g.flow_in(l))) {
+                if (level == 1 && l == 2 && g.skip == 0) {                 // fits both 16-map levels: decide by the order
+                    int partner = -1;
+                    for (const Dec &e : decs)
+                        if (&e != &d && e.kind == d.kind && e.n == d.n) partner = e.pos;
+                    if (partner < 0) { err = "one decoder for the two 16-map levels"; return false; }
+                    const bool earlier = back_to_front ? d.pos > partner : d.pos < partner;
+                    level = earlier ? 2 : 1;
+                    continue;
+                }
                 if (level) { err = "decoder input width " + std::to_string(d.n) + " fits two levels"; return false; }
                 level = l;
             }
@@ -392,6 +421,7 @@ bool load_t7_ex(const std::string &path, GraphOpts &g, bool infer, std::vector<f
         dec[{level, d.kind}] = std::move(d.convs);
         lmin = std::min(lmin, level);
     }
+    if (infer && g.skip == 0 && lmin != 1) { err = "level-1 convUnit but no level-1 decoder"; return false; }
     if (infer) g.skip = lmin - 1;
     else if (lmin != g.l_st()) { err = "the file's finest decoder level is " + std::to_string(lmin) + ", the graph options say " + std::to_string(g.l_st()); return false; }
     bool past_flow = false;

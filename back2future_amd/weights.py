@@ -21,7 +21,7 @@ LEVELS, L_ST, WIN = 7, 3, 9
 ND = 2 * WIN * WIN
 
 
-SHIPPED = dict(win=9, levels=7, skip=2, two_frame=0, sum_cvs=0, residual=0, occ_input=0, rescale_flow=0, flownet_factor=20.0)
+SHIPPED = dict(win=9, levels=7, skip=2, two_frame=0, sum_cvs=0, residual=0, occ_input=0, rescale_flow=0, flownet_factor=20.0, siamese=1)
 
 
 def graph_opts(**kw):
@@ -38,9 +38,19 @@ def opts_string(o):
     return ",".join("%s=%g" % (k, float(v)) for k, v in o.items())
 
 
+def feat_ch(l, o=SHIPPED):
+    """featMaps[l] of createModelMulti (pwc.lua:89,120-127): pwc_skip = 0 gives the level-1 unit 16 maps, pwc_siamese = 0 replaces
+    the learned pyramid by the (average-pooled) image: 3 maps on every level."""
+    if not o.get("siamese", 1):
+        return 3
+    if l == 1 and o["skip"] == 0:
+        return FEAT[2]
+    return FEAT[l]
+
+
 def occ_in_ch(l, o=SHIPPED):
     nd = o["win"] ** 2
-    n = (nd if o["two_frame"] else 2 * nd) + FEAT[l] + (FEAT[l] if o["two_frame"] else 0)
+    n = (nd if o["two_frame"] else 2 * nd) + feat_ch(l, o) + (feat_ch(l, o) if o["two_frame"] else 0)
     if l != o["levels"]:
         n += 2 + (2 if o["occ_input"] else 0)
     return n
@@ -49,22 +59,24 @@ def occ_in_ch(l, o=SHIPPED):
 def flow_in_ch(l, o=SHIPPED):
     nd = o["win"] ** 2
     ndf = nd if (o["two_frame"] or o["sum_cvs"]) else 2 * nd
-    return ndf if l == o["levels"] else ndf + FEAT[l] + 2
+    return ndf if l == o["levels"] else ndf + feat_ch(l, o) + 2
 
 
 def layout(past_flow, o=SHIPPED):
     """List of (name, shape, offset) in canonical order."""
     out, off = [], 0
-    LEVELS, L_ST = o["levels"], o["skip"] + 1
+    LEVELS, L_ST = o["levels"], max(o["skip"] + 1, 1)   # pwc.lua:136
 
     def add(name, shape):
         nonlocal off
         out.append((name, tuple(shape), off))
         off += int(np.prod(shape))
 
-    for l in range(2, LEVELS + 1):
-        add("feat%d.conv1.w" % l, (FEAT[l], FEAT[l - 1], 3, 3)); add("feat%d.conv1.b" % l, (FEAT[l],))
-        add("feat%d.conv2.w" % l, (FEAT[l], FEAT[l], 3, 3)); add("feat%d.conv2.b" % l, (FEAT[l],))
+    if o.get("siamese", 1):                               # pwc.lua:169-183: the level-1 unit only with pwc_skip = 0, none without the siamese net
+        for l in range(1 if o["skip"] == 0 else 2, LEVELS + 1):
+            ci, co = (3 if l == 1 else feat_ch(l - 1, o)), feat_ch(l, o)
+            add("feat%d.conv1.w" % l, (co, ci, 3, 3)); add("feat%d.conv1.b" % l, (co,))
+            add("feat%d.conv2.w" % l, (co, co, 3, 3)); add("feat%d.conv2.b" % l, (co,))
     for l in range(LEVELS, L_ST - 1, -1):
         kinds = [("occ", occ_in_ch(l, o)), ("flow", flow_in_ch(l, o))]
         if past_flow:

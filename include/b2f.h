@@ -60,13 +60,14 @@ B2F_API int b2f_version(void);
 B2F_API int b2f_init(const char *name_or_path, int device, b2f_ctx **out);
 /* Same with the graph shape of createModelMulti(opt) (models/pwc.lua:88-121) given explicitly, for models other
  * than the shipped ones: graph_opts = "win=5,levels=4" (createModelMulti(nil), pwc.lua:88), or any subset of
- * win (pwc_ws), levels, skip (pwc_skip, >= 1), two_frame, sum_cvs (pwc_sum_cvs), residual, occ_input,
- * rescale_flow, flownet_factor; NULL / "" = the shipped graph (opts.lua:83-98) -- or, for a ".t7" file, whatever
+ * win (pwc_ws), levels, skip (pwc_skip, >= 0), two_frame, sum_cvs (pwc_sum_cvs), residual, occ_input,
+ * rescale_flow, flownet_factor, siamese (pwc_siamese); NULL / "" = the shipped graph (opts.lua:83-98) -- or, for a ".t7" file, whatever
  * shape the file holds: win is read from its nn.CostVolMulti nodes (CostVolMulti.lua:26-37), levels and skip from the
  * convUnits / decoders in its node list (pwc.lua:136,237), the other options stay at their defaults; with graph_opts
- * given the file must be that graph.  frames = 3 and pwc_siamese = 1
- * are fixed.  Weights: "random:hard|soft[:seed[:gain]]", a ".t7" file or a .b2fw blob in the canonical order of that graph
- * (feature units l = 2..levels, then l = levels..skip+1 {occ, flow, [past-flow] decoder}).  Non-shipped shapes run
+ * given the file must be that graph.  frames = 3 is fixed; a pwc_siamese = 0 model (no convUnits: decoders of every
+ * level have the same shapes) is not read from .t7, only from flat weights.  Weights: "random:hard|soft[:seed[:gain]]", a ".t7" file or a .b2fw blob in the canonical order of that graph
+ * (feature units l = 2..levels -- from l = 1 with skip = 0, none with siamese = 0 --, then l = levels..skip+1 {occ, flow,
+ * [past-flow] decoder}).  Non-shipped shapes run
  * on a generic, untuned executor (every Lua node its own kernels); H and W of b2f_forward must then be multiples
  * of 2^(levels-1), computeFlow keeps the reference's /64 rounding.                                            */
 B2F_API int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2f_ctx **out);

@@ -510,6 +510,7 @@ typedef struct orc_opts {
     float flownet_factor; /* opt.flownet_factor :94,117      */
     int pruned;         /* not a reference option: 1 = compute only what computeFlow reads (est[1], est[3],
                            back2future.lua:77,87); the other output-table entries are left untouched */
+    int siamese;        /* opt.pwc_siamese   :99,115  (0: the average-pooled image instead of the learned pyramid, :125-127,182) */
 } orc_opts;
 
 static const int FEAT[8] = {0, 3, 16, 32, 64, 96, 128, 192}; /* featMaps, pwc.lua:29,89 */
@@ -519,12 +520,21 @@ ORC_API void orc_default_opts(orc_opts *o, int past_flow)
 {
     o->win = 9; o->levels = 7; o->skip = 2; o->two_frame = 0; o->sum_cvs = 0; o->residual = 0;
     o->occ_input = 0; o->rescale_flow = 0; o->past_flow = past_flow ? 1 : 0; o->flownet_factor = 20.f;
-    o->pruned = 0;
+    o->pruned = 0; o->siamese = 1;
+}
+
+/* featMaps[l] -- pwc.lua:89,120-127: pwc_skip = 0 gives the level-1 unit featMaps[2] maps; pwc_siamese = 0 makes every level the
+ * 3-channel image */
+static int featc(const orc_opts *o, int l)
+{
+    if (!o->siamese) return 3;
+    if (l == 1 && o->skip == 0) return FEAT[2];
+    return FEAT[l];
 }
 
 static int opts_ok(const orc_opts *o)
 {
-    return o->win >= 1 && (o->win & 1) && o->levels >= 2 && o->levels <= 7 && o->skip >= 1 && o->skip + 1 <= o->levels;
+    return o->win >= 1 && (o->win & 1) && o->levels >= 2 && o->levels <= 7 && o->skip >= 0 && o->skip + 1 <= o->levels;
 }
 
 static long conv_params(int ci, int co) { return (long)co * ci * 9 + co; }
@@ -541,19 +551,32 @@ static int nd_occ(const orc_opts *o) { return o->two_frame ? o->win * o->win : 2
 /* pwc.lua:288-305 */
 static int occ_in_ch(const orc_opts *o, int l)
 {
-    int n = nd_occ(o) + FEAT[l];
-    if (o->two_frame) n += FEAT[l];
+    int n = nd_occ(o) + featc(o, l);
+    if (o->two_frame) n += featc(o, l);
     if (l != o->levels) { n += 2; if (o->occ_input) n += 2; }
     return n;
 }
 /* pwc.lua:325-337 */
-static int flow_in_ch(const orc_opts *o, int l) { return l == o->levels ? nd_flow(o) : nd_flow(o) + FEAT[l] + 2; }
+static int flow_in_ch(const orc_opts *o, int l) { return l == o->levels ? nd_flow(o) : nd_flow(o) + featc(o, l) + 2; }
+
+/* the feature units in graph-construction order -- pwc.lua:169-183: [level 1 with pwc_skip = 0], levels 2..levels; none without
+ * the siamese net */
+static long feat_params(const orc_opts *o)
+{
+    long s = 0;
+    if (!o->siamese) return 0;
+    for (int l = (o->skip == 0 ? 1 : 2); l <= o->levels; ++l) {
+        const int ci = (l == 1) ? 3 : featc(o, l - 1), co = featc(o, l);
+        s += conv_params(ci, co) + conv_params(co, co);
+    }
+    return s;
+}
 
 ORC_API long orc_param_count_ex(const orc_opts *o)
 {
     if (!opts_ok(o)) return -1;
     long s = 0;
-    for (int l = 2; l <= o->levels; ++l) s += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
+    s += feat_params(o);
     for (int l = o->levels; l >= o->skip + 1; --l) {
         s += decoder_params(occ_in_ch(o, l)) + decoder_params(flow_in_ch(o, l));
         if (o->past_flow) s += decoder_params(flow_in_ch(o, l));
@@ -571,12 +594,12 @@ ORC_API long orc_param_count(int past_flow)
 static float *falloc(long n) { return (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1)); }
 
 /* convUnit -- pwc.lua:58-65 */
-static const float *conv_unit(const float *x, int B, int ci, int co, int H, int W,
+static const float *conv_unit(const float *x, int B, int ci, int co, int H, int W, int stride,
                               const float *p, float *tmp, float *y)
 {
     const float *w1 = p, *b1 = w1 + (long)co * ci * 9, *w2 = b1 + co, *b2 = w2 + (long)co * co * 9;
-    orc_conv3x3(x, B, ci, H, W, w1, b1, co, 2, 1, tmp);
-    orc_conv3x3(tmp, B, co, H / 2, W / 2, w2, b2, co, 1, 1, y);
+    orc_conv3x3(x, B, ci, H, W, w1, b1, co, stride, 1, tmp);
+    orc_conv3x3(tmp, B, co, H / stride, W / stride, w2, b2, co, 1, 1, y);
     return b2 + co;
 }
 
@@ -671,23 +694,31 @@ ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float 
     /* siamese feature pyramid, shared weights -- pwc.lua:169-211; frames f_i..l_i only */
     const float *p = params;
     {
-        const float *pn = p;
-        for (int l = 2; l <= LEVELS; ++l) pn += conv_params(FEAT[l - 1], FEAT[l]) + conv_params(FEAT[l], FEAT[l]);
         for (int f = f_i; f <= l_i; ++f) {
-            cs[f][1] = Is[f];
+            cs[f][1] = Is[f];                                   /* :204 (nn.Identity with pwc_siamese = 0, :175) */
             const float *q = p;
+            if (o->siamese && o->skip == 0) {                   /* :171-173,202-203: convUnit(3, featMaps[1], 1) */
+                float *tmp = falloc((long)B * featc(o, 1) * HW);
+                cs[f][1] = falloc((long)B * featc(o, 1) * HW);
+                q = conv_unit(Is[f], B, 3, featc(o, 1), H, W, 1, q, tmp, cs[f][1]);
+                free(tmp);
+            }
             for (int l = 2; l <= LEVELS; ++l) {
-                float *tmp = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
-                cs[f][l] = falloc((long)B * FEAT[l] * hh[l] * wl[l]);
-                q = conv_unit(cs[f][l - 1], B, FEAT[l - 1], FEAT[l], hh[l - 1], wl[l - 1], q, tmp, cs[f][l]);
+                cs[f][l] = falloc((long)B * featc(o, l) * hh[l] * wl[l]);
+                if (!o->siamese) {                              /* :182: nn.SpatialAveragePooling(2,2,2,2) */
+                    orc_avgpool2(cs[f][l - 1], B * 3, hh[l - 1], wl[l - 1], cs[f][l]);
+                    continue;
+                }
+                float *tmp = falloc((long)B * featc(o, l) * hh[l] * wl[l]);
+                q = conv_unit(cs[f][l - 1], B, featc(o, l - 1), featc(o, l), hh[l - 1], wl[l - 1], 2, q, tmp, cs[f][l]);
                 free(tmp);
             }
         }
-        p = pn;
+        p += feat_params(o);
     }
 
     for (int l = LEVELS; l >= L_ST; --l) { /* pwc.lua:237 */
-        const int h = hh[l], w = wl[l], C = FEAT[l];
+        const int h = hh[l], w = wl[l], C = featc(o, l);
         const long hw = (long)h * w;
         /* :238-244: raw features on the coarsest level, warped ones below */
         const float *in_fut = (l == LEVELS) ? cs[3][l] : ws[3][l];
@@ -780,6 +811,7 @@ ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float 
         for (int pass = 0; pass < 2; ++pass) {
             float **src = pass ? bfs : fs, **u = pass ? ubfs : ufs, **sk = pass ? skip_ubfs : skip_ufs;
             if (!src[l]) continue;
+            if (o->skip == 0 && l == L_ST) continue;            /* :359: "if skip > 0 or l > l_st" */
             u[l] = falloc((long)B * 2 * hw * 4);
             orc_upsample_bilinear2x(src[l], B * 2, h, w, u[l]);
             if (o->rescale_flow) for (long i = 0; i < (long)B * 2 * hw * 4; ++i) u[l][i] = u[l][i] * 2.0f; /* :365-369 */
@@ -800,12 +832,13 @@ ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float 
             if (l > L_ST && f >= f_i && f <= l_i) { /* :395-408 */
                 const float k = o->rescale_flow ? (float)((double)o->flownet_factor * (f - ref))
                                                 : (float)((double)o->flownet_factor * (f - ref) / pow(2, l - 2));
-                ws[f][l - 1] = falloc((long)B * FEAT[l - 1] * hw * 4);
-                warping_unit(cs[f][l - 1], ufs[l], k, B, FEAT[l - 1], 2 * h, 2 * w, ws[f][l - 1]);
+                ws[f][l - 1] = falloc((long)B * featc(o, l - 1) * hw * 4);
+                warping_unit(cs[f][l - 1], ufs[l], k, B, featc(o, l - 1), 2 * h, 2 * w, ws[f][l - 1]);
             }
             /* :422-446: image warp with skip_u(b)fs */
             if (pruned && !(l == L_ST && f == 1 && !o->past_flow)) continue;
             const float *tmp = (o->past_flow && f < ref) ? skip_ubfs[l] : skip_ufs[l];
+            if (o->skip == 0) tmp = (o->past_flow && f < ref) ? bfs[l] : fs[l];   /* :423-429 */
             const float k2 = o->rescale_flow ? (float)((double)o->flownet_factor * (f - ref))
                                              : (float)((double)o->flownet_factor * (f - ref) / pow(2, l - L_ST));
             const int uh = H >> (l - L_ST), uw = W >> (l - L_ST);
@@ -818,10 +851,13 @@ ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float 
     int no = 0;
     for (int l = L_ST; l <= LEVELS; ++l) {
         const long px = (long)B * (H >> (l - L_ST)) * (W >> (l - L_ST));
-        if (skip_ufs[l] && (!pruned || l == L_ST)) memcpy(outs[no], skip_ufs[l], sizeof(float) * 2 * px);
+        /* :462-471: with pwc_skip = 0 the level's own maps, not the upsampled ones */
+        const float *o_f = o->skip == 0 ? fs[l] : skip_ufs[l], *o_b = o->skip == 0 ? bfs[l] : skip_ubfs[l];
+        const float *o_o = o->skip == 0 ? occs[l] : skip_occs[l];
+        if (o_f && (!pruned || l == L_ST)) memcpy(outs[no], o_f, sizeof(float) * 2 * px);
         ++no;
-        if (o->past_flow) { if (skip_ubfs[l]) memcpy(outs[no], skip_ubfs[l], sizeof(float) * 2 * px); ++no; }
-        if (skip_occs[l] && (!pruned || l == L_ST)) memcpy(outs[no], skip_occs[l], sizeof(float) * 2 * px);
+        if (o->past_flow) { if (o_b) memcpy(outs[no], o_b, sizeof(float) * 2 * px); ++no; }
+        if (o_o && (!pruned || l == L_ST)) memcpy(outs[no], o_o, sizeof(float) * 2 * px);
         ++no;
         if (iws[1][l]) memcpy(outs[no], iws[1][l], sizeof(float) * 3 * px);
         ++no;
@@ -832,7 +868,8 @@ ORC_API int orc_pwc_forward_ex(const float *x, int B, int H, int W, const float 
     for (int f = 1; f <= frames; ++f) {
         free(Is[f]);
         for (int k = 2; k < 8; ++k) free(ds[f][k]);
-        for (int l = 2; l <= 7; ++l) { free(cs[f][l]); free(ws[f][l]); }
+        if (cs[f][1] != Is[f]) free(cs[f][1]);
+        for (int l = 1; l <= 7; ++l) { if (l > 1) free(cs[f][l]); free(ws[f][l]); }
         for (int l = 0; l < 9; ++l) free(iws[f][l]);
     }
     for (int l = 0; l < 9; ++l) {

@@ -44,7 +44,7 @@ class Opts(C.Structure):
     """struct orc_opts of b2f_oracle.c: the option table of createModelMulti (pwc.lua:88-121)."""
     _fields_ = [("win", C.c_int), ("levels", C.c_int), ("skip", C.c_int), ("two_frame", C.c_int),
                 ("sum_cvs", C.c_int), ("residual", C.c_int), ("occ_input", C.c_int), ("rescale_flow", C.c_int),
-                ("past_flow", C.c_int), ("flownet_factor", C.c_float), ("pruned", C.c_int)]
+                ("past_flow", C.c_int), ("flownet_factor", C.c_float), ("pruned", C.c_int), ("siamese", C.c_int)]
 
 
 def opts(past_flow=False, **kw):

@@ -172,11 +172,11 @@ def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False, o=None):
     cs, shares = {}, {}
     for f in (1, 2, 3):
         cs[f] = {1: Is[f]}
-        for l in range(2, LV + 1):
-            c1, s1 = _conv(cp, tcls, scls, v["feat%d.conv1.w" % l], v["feat%d.conv1.b" % l], 2, shares.get((l, 1)))
+        for l in range(1 if SK == 0 else 2, LV + 1):       # pwc_skip = 0: convUnit(3, 16, 1) on level 1 (pwc.lua:171-173)
+            c1, s1 = _conv(cp, tcls, scls, v["feat%d.conv1.w" % l], v["feat%d.conv1.b" % l], 1 if l == 1 else 2, shares.get((l, 1)))
             c2, s2 = _conv(cp, tcls, scls, v["feat%d.conv2.w" % l], v["feat%d.conv2.b" % l], 1, shares.get((l, 2)))
             shares[(l, 1)], shares[(l, 2)] = s1, s2
-            cs[f][l] = node(seq([c1, lrelu(), c2, lrelu()]), cs[f][l - 1])
+            cs[f][l] = node(seq([c1, lrelu(), c2, lrelu()]), Is[f] if l == 1 else cs[f][l - 1])
 
     def decoder(l, kind):
         mods = []
@@ -214,13 +214,13 @@ def build_model(flat, past_flow, cuda=True, cudnn=True, dpt=False, o=None):
         else:
             fs = node(decoder(l, "flow"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ufs[l + 1]))
             bfs = node(decoder(l, "past"), node(TorchObj("nn.JoinTable", dimension=2), cv, cs[2][l], ubfs[l + 1])) if past_flow else None
-        ufs[l] = up(fs)
-        skip_u = ufs[l]
+        ufs[l] = up(fs) if (SK > 0 or l > 1) else None        # pwc.lua:359
+        skip_u = ufs[l] if SK > 0 else fs                    # pwc.lua:423-429,462-466
         for _ in range(SK - 1):
             skip_u = up(skip_u)
         if past_flow:
-            ubfs[l] = up(bfs)
-            skip_ub = ubfs[l]
+            ubfs[l] = up(bfs) if (SK > 0 or l > 1) else None
+            skip_ub = ubfs[l] if SK > 0 else bfs
             for _ in range(SK - 1):
                 skip_ub = up(skip_ub)
         iws = {}
@@ -246,14 +246,14 @@ def save(path, flat, past_flow, **kw):
         Writer(f).obj(build_model(flat, past_flow, **kw))
 
 
-def build_model_legacy(flat, past_flow, replicas=2):
+def build_model_legacy(flat, past_flow, replicas=2, o=None):
     """A structurally different serialization of the same network, as an older / differently trained checkpoint could
     look: plain nn.* classes on torch.FloatTensor, ALL parameters as views (offset + strides) into ONE flat storage (what
     model:getParameters() leaves behind), convolution weights as 2-D Co x (Ci*9) views (SpatialConvolutionMM-style),
     the bias of every other conv as a strided view, double-precision MulConstant-irrelevant extras, unknown fields,
     serialized functions of all three tags, forward nodes in reverse order, and an nn.DataParallelTable with `replicas`
     gModules (back2future.lua:114-116 takes the first)."""
-    g = build_model(flat, past_flow, cuda=False, cudnn=False, dpt=False)
+    g = build_model(flat, past_flow, cuda=False, cudnn=False, dpt=False, o=o)
     flatv = np.asarray(flat, np.float32)
     convs = []
     seen = set()

@@ -104,3 +104,31 @@ def test_non_shipped_graph_from_a_t7_file(tmp_path):
     finally:
         a.close()
         b.close()
+
+
+def test_skip0_graph_from_a_t7_file_through_compute_flow(tmp_path):
+    """pwc_skip = 0 (pwc.lua:120-122,171-173,423-429,462-471) end to end: the graph shape out of a .t7 (level-1 convUnit, the equally
+    wide decoders of levels 1 and 2 told apart by the node order), est[1] = fs[1] / est[3] = occs[1] at full resolution through the
+    computeFlow boundary against the oracle's output table."""
+    from tests import t7_writer
+    o = W.graph_opts(win=3, levels=4, skip=0)
+    flat = W.random_init(5, True, 2.0, o)
+    p = str(tmp_path / "skip0.t7")
+    with open(p, "wb") as f:
+        t7_writer.Writer(f).obj(t7_writer.build_model(flat, True, o=o))
+    m = back2future.Model(p)
+    try:
+        assert (m.levels, m.win, m.past_flow, m.n_outputs) == (4, 3, True, 20)
+        np.testing.assert_array_equal(m.get_weights(), flat)
+        rng = np.random.default_rng(2)
+        ims = [rng.random((3, 64, 128), dtype=np.float32) for _ in range(3)]
+        flow, fo, bo = m.computeFlow(*ims)
+        xn = back2future.normalize(np.concatenate(ims, 0))[None]
+        table = O.pwc_forward(xn, flat, True, _oracle_opts(o, True))
+        assert table[0].shape == (1, 2, 64, 128) and np.abs(table[0][0]).max() > 0.02
+        assert np.abs(flow - table[0][0].astype(np.float64)).max() <= 1e-3
+        near = np.abs(table[2][0] - 0.6666) < 1e-3
+        assert ((fo[0] != (table[2][0][1] >= 0.6666)) & ~near[1]).sum() == 0
+        assert ((bo[0] != (table[2][0][0] >= 0.6666)) & ~near[0]).sum() == 0
+    finally:
+        m.close()

@@ -21,13 +21,17 @@ CASES = {
     "two_frame": dict(win=5, levels=4, two_frame=1),                                  # :160-165, :279-284, :292-296
     "skip1+factor": dict(win=3, levels=4, skip=1, flownet_factor=10.0),               # :136, :404
     "skip3": dict(win=3, levels=5, skip=3, residual=1, sum_cvs=1),
+    "skip0": dict(win=3, levels=3, skip=0),                                           # :120-122,171-173,359,423-429,462-471
+    "skip0+occ_input+rescale": dict(win=3, levels=3, skip=0, occ_input=1, rescale_flow=1),
+    "no_siamese": dict(win=5, levels=4, siamese=0),                                   # :125-127,175,182
+    "skip0+no_siamese+two_frame": dict(win=3, levels=3, skip=0, siamese=0, two_frame=1),
 }
 
 
 def _oracle_opts(o, past):
     return O.opts(past, win=o["win"], levels=o["levels"], skip=o["skip"], two_frame=o["two_frame"], sum_cvs=o["sum_cvs"],
                   residual=o["residual"], occ_input=o["occ_input"], rescale_flow=o["rescale_flow"],
-                  flownet_factor=o["flownet_factor"])
+                  flownet_factor=o["flownet_factor"], siamese=o["siamese"])
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -103,7 +103,7 @@ def load_t7_ex(path, graph=None):
     return out, dict(kv.split("=") for kv in opts.value.decode().split(","))
 
 
-@pytest.mark.parametrize("win,levels,skip,past", [(5, 4, 2, True), (7, 5, 1, False), (3, 6, 3, True), (9, 7, 2, False)])
+@pytest.mark.parametrize("win,levels,skip,past", [(5, 4, 2, True), (7, 5, 1, False), (3, 6, 3, True), (9, 7, 2, False), (3, 4, 0, True), (5, 2, 0, False)])
 def test_other_graph_shapes_are_read_from_the_file(tmp_path, win, levels, skip, past):
     """createModelMulti(opt) with another window / number of levels / pwc_skip saved as .t7: the reader takes win from the
     nn.CostVolMulti nodes' win field (CostVolMulti.lua:26-37), levels from the convUnits and skip from the decoder levels in the
@@ -124,9 +124,25 @@ def test_other_graph_shapes_are_read_from_the_file(tmp_path, win, levels, skip, 
     if levels > 2:
         with pytest.raises(_lib.B2FError, match="levels"):
             load_t7_ex(p, "win=%d,levels=%d,skip=%d" % (win, levels - 1, min(skip, levels - 2)))
+    if skip == 0:   # pwc_skip = 0 files carry a level-1 convUnit (pwc.lua:171-173); levels 1 and 2 are told apart by the node order
+        with pytest.raises(_lib.B2FError, match="level-1 convUnit"):
+            load_t7_ex(p, "win=%d,levels=%d,skip=1" % (win, levels))
     # b2f_load_t7 (no options) stays the loader of the shipped shape
     if (win, levels, skip) == (9, 7, 2):
         np.testing.assert_array_equal(load_t7(p)[0], flat)
     else:
         with pytest.raises(_lib.B2FError):
             load_t7(p)
+
+
+@pytest.mark.parametrize("past", [False, True])
+def test_skip0_file_written_back_to_front(tmp_path, past):
+    """pwc_skip = 0 (pwc.lua:120-122): levels 1 and 2 both carry 16 maps, so their decoders have the same shapes and the reader
+    tells them apart by the node order -- also in a file whose forward nodes are stored in reverse."""
+    o = W.graph_opts(win=3, levels=4, skip=0)
+    flat = W.random_init(23, past, 1.0, o)
+    p = str(tmp_path / "m.t7")
+    t7_writer.save_legacy(p, flat, past, o=o)
+    got, opts = load_t7_ex(p)
+    assert (int(opts["win"]), int(opts["levels"]), int(opts["skip"]), int(opts["past_flow"])) == (3, 4, 0, int(past))
+    np.testing.assert_array_equal(got, flat)

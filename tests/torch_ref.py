@@ -83,6 +83,7 @@ def pwc_forward(x, wv, past_flow, dtype=torch.float64, o=None):
     from back2future_amd import weights as Wt
     o = o or Wt.SHIPPED
     L, LST, win = o["levels"], o["skip"] + 1, o["win"]
+    siam, skip0 = o.get("siamese", 1), o["skip"] == 0
     ff = float(o["flownet_factor"])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     x = t(x)
@@ -97,7 +98,13 @@ def pwc_forward(x, wv, past_flow, dtype=torch.float64, o=None):
     cs = {}
     for f in frames:
         cs[f] = {1: Is[f]}
+        if skip0 and siam:                                 # pwc.lua:171-177,202-203: convUnit(3, 16, 1) on the image
+            a = _conv(Is[f], P["feat1.conv1.w"], P["feat1.conv1.b"], 1)
+            cs[f][1] = _conv(a, P["feat1.conv2.w"], P["feat1.conv2.b"], 1)
         for l in range(2, L + 1):
+            if not siam:                                   # pwc.lua:182: nn.SpatialAveragePooling(2,2,2,2) instead of the convUnit
+                cs[f][l] = F.avg_pool2d(cs[f][l - 1], 2)
+                continue
             a = _conv(cs[f][l - 1], P["feat%d.conv1.w" % l], P["feat%d.conv1.b" % l], 2)
             cs[f][l] = _conv(a, P["feat%d.conv2.w" % l], P["feat%d.conv2.b" % l], 1)
 
@@ -155,6 +162,10 @@ def pwc_forward(x, wv, past_flow, dtype=torch.float64, o=None):
             sk_ub[l] = ubfs[l]
             for _ in range(2, LST):
                 sk_ub[l] = up(sk_ub[l]) * mul
+        if skip0:                                          # pwc.lua:423-429,462-471: the level's own maps are the outputs
+            sk_u[l], sk_o[l] = fs[l], occs[l]
+            if past_flow:
+                sk_ub[l] = bfs[l]
         for f in (1, 3):
             if l > LST and f in frames:
                 k = ff * (f - 2) if o["rescale_flow"] else ff * (f - 2) / 2 ** (l - 2)
