@@ -1036,8 +1036,8 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
-        if (key[5] == 'v' && !B2F_EXPERIMENTS && (value == 2 || value == 4 || value == 6))
-            return fail("b2f_set_option: corr_variant 2 / 4 / 6 are experiment kernels: build with `python -m back2future_amd.build --experiments`");
+        if (key[5] == 'v' && !B2F_EXPERIMENTS && (value == 2 || value == 4 || value == 6 || value == 8))
+            return fail("b2f_set_option: corr_variant 2 / 4 / 6 / 8 are experiment kernels: build with `python -m back2future_amd.build --experiments`");
         (key[5] == 'v' ? c->corr_variant : c->corr_ablate) = value;
     } else if (!strcmp(key, "op_wino_split")) c->op_wino_split = value;
     else if (!strcmp(key, "host_subbatch_pixels")) c->host_subbatch_pixels = value > 0 ? value : (16ll << 20);

@@ -539,6 +539,241 @@ __global__ __launch_bounds__(128 * NDIR, 2) void warp_costvol_2px_kernel(const C
 }
 
 
+#if B2F_EXPERIMENTS   // variant 8 (four pixels x three qx columns per thread): measured slower than variant 3, profiles/r05_corr_notes.txt
+// ======================================================================================================
+// Four-pixel variant (round 5, variant 8).  What the two-pixel kernel is short of is issue slots and LDS bandwidth, both for the
+// same reason: 2 x 81 accumulators per thread leave two waves per SIMD (one VALU instruction every ~2.75 cycles where the pipe takes
+// one every 1.67: tools/fma_rate.hip) and one ds_read_b128 per 7.2 FMAs (levels 3 + 4 read 34 GB of LDS per step: 0.5 ms of the
+// 0.97 at 128 B/clk).  Here a thread owns FOUR vertically adjacent pixels but only THREE of the nine qx columns -- wave g of a
+// 192-thread block takes qx = 3g - 4 .. 3g - 2 for all 64 pixel quads of the 16 x 16 tile: 4 x 27 = 108 accumulators (three waves
+// per SIMD, four blocks = twelve waves per CU), a neighbour row serves up to four pixels (12 rows x 3 reads feed 432 FMAs per channel
+// quad: one read per 12 FMAs).  Halo, sampling records, gather, L2 prefetch and the order of every accumulator's operations are the
+// two-pixel kernel's: identical results.  One direction per block.  A thread's 27 channels are not a whole number of 8-float
+// records: the records shared by two column groups (3 and 6 of a direction's ten) are written in pieces by both.
+// MEASURED (batch 16, levels 3 / 4 / 5): 0.826 / 0.337 / 0.179 ms against 0.695 / 0.301 / 0.121 of the two-pixel kernel -- the premise
+// was wrong.  Ablations at level 3 (p.ablate: 1 no tap loads, 2 no FMAs, 4 no stores, 16 no reference loads, 32 no L2 prefetch):
+// stores 0.32 ms, reference loads 0.18 (read by three waves here), tap loads 0.12, FMAs 0.06, skeleton 0.17 -- the parts ADD UP to
+// the total, and starting the co-resident blocks out of phase changes nothing: one shared resource, the CU's vector-memory path
+// (loads and stores together), not issue slots or LDS bandwidth.  Experiments build only.
+template <bool POW2>
+__global__ __launch_bounds__(192, 3) void warp_costvol_4px_kernel(const CorrLaunch p)
+{
+    using namespace v2;
+    constexpr int NTHR = 192;
+    constexpr int NG = NH2 / NTHR;                     // sampling-record rounds: 3 (576 halo pixels)
+    constexpr int NIT = NH2 * 2 / NTHR;                // gather items (halo pixel, k4) per thread and chunk: 6
+    static_assert(NG * NTHR == NH2 && NIT * NTHR == 2 * NH2, "halo must divide evenly");
+    __shared__ __attribute__((aligned(16))) float4 nb[2][PL2];             // [k4][pixel] 24 KB
+    __shared__ float4 samp_w[NH2];                                         // 9 KB
+    __shared__ SampIdx samp_i[NH2];                                        // 4.5 KB
+    __shared__ float pf_sink[192];                                         // landing zone of the L2 prefetch (never read)
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.w + TW2 - 1) / TW2, tiles_y = (p.h + TH2 - 1) / TH2;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int dir = bid & 1;                           // 0 fwd / future map, 1 bwd / past map
+    bid >>= 1;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx_i * TW2, y0 = ty_i * TH2;
+
+    const float *ref = p.ref + (size_t)b * p.img_stride;
+    const float *nbr = (dir == 0 ? p.nbr_fut : p.nbr_past) + (size_t)b * p.img_stride;
+
+    // ---- sampling records for the halo (once per block), flow loads issued together
+    {
+        float2 fl[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int hp = tid + j * NTHR;
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
+            fl[j] = make_float2(0.f, 0.f);
+            if (p.flow) fl[j] = *reinterpret_cast<const float2 *>(p.flow + ((size_t)b * p.h * p.w + (in ? (size_t)y * p.w + x : 0)) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int hp = tid + j * NTHR;
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int y = y0 - R + hy, x = x0 - R + hx;
+            float4 wgt = make_float4(0.f, 0.f, 0.f, 0.f);
+            SampIdx si;
+            si.idx = 0; si.flags = 0;
+            if (y >= 0 && y < p.h && x >= 0 && x < p.w) {
+                const float k = dir == 0 ? p.k : -p.k;   // nn.MulConstant(20*(f-ref)/2^(l-2)), pwc.lua:404
+                const float u = fl[j].x * k, v = fl[j].y * k;
+                int xl, yt;
+                float wx, wy;
+                bhwd_top_left(u + (float)x, p.w, xl, wx);
+                bhwd_top_left(v + (float)y, p.h, yt, wy);
+                si.idx = (yt * p.w + xl) * p.pix_stride;
+                si.flags = ((xl + 1 <= p.w - 1) ? 1 : 0) | ((yt + 1 <= p.h - 1) ? 2 : 0);
+                wgt = make_float4(wx * wy, (1.f - wx) * wy, wx * (1.f - wy), (1.f - wx) * (1.f - wy));
+            }
+            si.flags |= (hy * HP2 + hx) << 2;   // LDS slot of this halo pixel (k4 = 0 plane)
+            samp_w[hp] = wgt;
+            samp_i[hp] = si;
+        }
+    }
+
+    float acc[4][27];   // [pixel of the quad][(qx - (3 grp - 4)) * 9 + qy + 4]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 27; ++i) acc[r][i] = 0.f;
+
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);   // qx column group of this wave
+    const int lane = tid & 63;
+    const int tyq = lane >> 4, lx = lane & 15;
+    const int py0 = y0 + 4 * tyq, px = x0 + lx;
+    const float *refp[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) refp[r] = ref + (size_t)((py0 + r < p.h && px < p.w) ? ((py0 + r) * p.w + px) : 0) * p.pix_stride;
+    // neighbour (row f, column jj of the group) of the quad: LDS pixel (4 tyq + R + f, lx + R - qx), qx = 3 grp - 4 + jj
+    const float4 *myn = &nb[0][(4 * tyq + R) * HP2 + (lx + R + 4 - 3 * grp)];
+
+    __syncthreads();
+    const int nchunk = p.C >> 3;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const size_t coff = (size_t)ch * p.chunk_stride;
+        // ---- gather + blend the warped halo chunk into LDS (the two-pixel kernel's: lanes 2i / 2i + 1 fetch the two 16-byte
+        // halves of a pixel's chunk); two items = 8 loads in flight per thread, 1 536 per block as there
+        const int gk4 = tid & 1;
+#pragma unroll 1
+        for (int j0 = 0; j0 < NIT; j0 += 2) {
+            float4 t[2][4], wg[2];
+            int slot[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int q = (tid >> 1) + (NTHR / 2) * (j0 + jj);
+                wg[jj] = samp_w[q];
+                const SampIdx si = samp_i[q];
+                const float *src = nbr + coff + si.idx + 4 * gk4;
+                const int dx = (si.flags & 1) * p.pix_stride, dy = (si.flags & 2) ? p.w * p.pix_stride : 0;
+                slot[jj] = (si.flags >> 2) + gk4 * PL2;
+                if (p.ablate & 1) { t[jj][0] = t[jj][1] = t[jj][2] = t[jj][3] = wg[jj]; continue; }
+                t[jj][0] = *reinterpret_cast<const float4 *>(src);
+                t[jj][1] = *reinterpret_cast<const float4 *>(src + dx);
+                t[jj][2] = *reinterpret_cast<const float4 *>(src + dy);
+                t[jj][3] = *reinterpret_cast<const float4 *>(src + dy + dx);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float4 w4 = wg[jj], tl = t[jj][0], tr = t[jj][1], bl = t[jj][2], br = t[jj][3];
+                float4 v;
+                v.x = fmaf(w4.w, br.x, fmaf(w4.z, bl.x, fmaf(w4.y, tr.x, w4.x * tl.x)));
+                v.y = fmaf(w4.w, br.y, fmaf(w4.z, bl.y, fmaf(w4.y, tr.y, w4.x * tl.y)));
+                v.z = fmaf(w4.w, br.z, fmaf(w4.z, bl.z, fmaf(w4.y, tr.z, w4.x * tl.z)));
+                v.w = fmaf(w4.w, br.w, fmaf(w4.z, bl.w, fmaf(w4.y, tr.w, w4.x * tl.w)));
+                (&nb[0][0])[slot[jj]] = v;
+            }
+        }
+        float4 rf[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.ablate & 16) { rf[r][0] = rf[r][1] = make_float4((float)ch, 1.f, 2.f, (float)r); continue; }
+            rf[r][0] = *reinterpret_cast<const float4 *>(refp[r] + coff);
+            rf[r][1] = *reinterpret_cast<const float4 *>(refp[r] + coff + 4);
+        }
+        __syncthreads();
+        // ---- L2 prefetch of the NEXT chunk's source window under this chunk's FMAs (see the two-pixel kernel)
+        asm volatile("" :: "v"(rf[0][0].x), "v"(rf[1][0].x), "v"(rf[2][0].x), "v"(rf[3][0].x), "v"(rf[0][1].x), "v"(rf[1][1].x), "v"(rf[2][1].x), "v"(rf[3][1].x));
+        if (ch + 1 < nchunk && tid < 64 && !(p.ablate & 32)) {
+            const float *nbase = nbr + coff + p.chunk_stride;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int i = tid + 64 * it;
+                const int r = min(i / 7, HH2), sg = i - (i / 7) * 7;
+                const SampIdx si = samp_i[min(r, HH2 - 1) * HW2 + min(4 * sg, HW2 - 1)];
+                const float *a = nbase + si.idx + (r == HH2 ? p.w * p.pix_stride : 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a,
+                                                 (__attribute__((address_space(3))) void *)(pf_sink + it * 64), 4, 0, 0);
+            }
+        }
+        // ---- correlate: 24 steps = 2 k4 x 12 neighbour rows f = -4..7; row f is qy = r - f of pixel r of the quad
+        // (fwd volume: neighbour at (y - qy, x - qx), CostVolMulti.lua:76-87)
+        if (!(p.ablate & 2))
+#pragma unroll
+        for (int st = 0; st < 24; ++st) {
+            const int k4 = st / 12, f = st - 12 * k4 - 4;
+            float4 cur[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) cur[jj] = myn[k4 * PL2 + f * HP2 - jj];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qy = r - f;
+                if (qy < -4 || qy > 4) continue;
+                const float4 rv = rf[r][k4];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    float a = acc[r][jj * 9 + qy + 4];
+                    a = fmaf(rv.x, cur[jj].x, a);
+                    a = fmaf(rv.y, cur[jj].y, a);
+                    a = fmaf(rv.z, cur[jj].z, a);
+                    a = fmaf(rv.w, cur[jj].w, a);
+                    acc[r][jj * 9 + qy + 4] = a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- scale by 1/C (output:div(N), CostVolMulti.lua:100) and store this wave's 27 channels of the four pixels.  Channel of
+    // accumulator i: 27 grp + i in the fwd volume, 80 - (27 grp + i) in the bwd one (mirrored window); cb = first channel / 27.
+    const float cf = (float)p.C, inv = 1.f / cf;
+    const int cb = dir == 0 ? grp : 2 - grp;
+    if ((p.ablate & 4) && acc[0][0] != 12345.678f) return;   // profiling only: drop the stores, keep acc live
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int py = py0 + r;
+        if (!(py < p.h && px < p.w)) continue;
+        float v[27];                                   // ascending channel order: v[i] = channel 27 cb + i
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+            const float a = dir == 0 ? acc[r][i] : acc[r][26 - i];
+            v[i] = POW2 ? a * inv : a / cf;
+        }
+        const size_t pix = (size_t)py * p.w + px;
+        float *o = p.out + (size_t)b * p.out_img_stride + pix * p.out_pix_stride + (size_t)(dir * 10) * p.out_chunk_stride;
+        auto rec = [&](int j) { return o + (size_t)j * p.out_chunk_stride; };
+        auto full = [&](int j, int i0) {               // record j = v[i0 .. i0 + 7]
+            *reinterpret_cast<float4 *>(rec(j)) = make_float4(v[i0], v[i0 + 1], v[i0 + 2], v[i0 + 3]);
+            *reinterpret_cast<float4 *>(rec(j) + 4) = make_float4(v[i0 + 4], v[i0 + 5], v[i0 + 6], v[i0 + 7]);
+        };
+        if (cb == 0) {                                 // channels 0..26: records 0, 1, 2, slots 0..2 of record 3
+            full(0, 0); full(1, 8); full(2, 16);
+            *reinterpret_cast<float2 *>(rec(3)) = make_float2(v[24], v[25]);
+            rec(3)[2] = v[26];
+        } else if (cb == 1) {                          // channels 27..53: slots 3..7 of record 3, records 4, 5, slots 0..5 of record 6
+            rec(3)[3] = v[0];
+            *reinterpret_cast<float4 *>(rec(3) + 4) = make_float4(v[1], v[2], v[3], v[4]);
+            full(4, 5); full(5, 13);
+            *reinterpret_cast<float4 *>(rec(6)) = make_float4(v[21], v[22], v[23], v[24]);
+            *reinterpret_cast<float2 *>(rec(6) + 4) = make_float2(v[25], v[26]);
+        } else {                                       // channels 54..80: slots 6, 7 of record 6, records 7, 8, 9, channel 80
+            *reinterpret_cast<float2 *>(rec(6) + 6) = make_float2(v[0], v[1]);
+            full(7, 2); full(8, 10); full(9, 18);
+            float *ol = p.out + (size_t)b * p.out_img_stride + pix * p.out_pix_stride + (size_t)20 * p.out_chunk_stride;   // [fwd80, bwd80, u, v, ub, vb, 0, 0]
+            if (dir == 0) {
+                ol[0] = v[26];
+            } else {
+                const size_t fp = ((size_t)b * p.h * p.w + pix) * 2;
+                float2 f = make_float2(0.f, 0.f), fb = make_float2(0.f, 0.f);
+                if (p.flow) f = *reinterpret_cast<const float2 *>(p.flow + fp);
+                if (p.flow_b) fb = *reinterpret_cast<const float2 *>(p.flow_b + fp);
+                ol[1] = v[26];
+                ol[2] = f.x; ol[3] = f.y;
+                *reinterpret_cast<float4 *>(ol + 4) = make_float4(fb.x, fb.y, 0.f, 0.f);
+            }
+        }
+    }
+}
+#endif  // B2F_EXPERIMENTS (variant 8)
+
+
 // ======================================================================================================
 // Window-staged variant (round 2, variant 4): the gather of the two-pixel kernel issues four 16-byte tap loads per
 // halo pixel and chunk half through the vector memory pipe -- 9x the bytes of the source window they come from -- in
@@ -857,6 +1092,7 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     //      per-phase LDS latency chains (profiles/r02_corr_experiments.txt (10))
     //   5  the persistent "unit" form of b2f_corr5.hip (C a multiple of 16; other C run variant 3)
     //   6  its role-specialised form (FMA waves / gather waves with the LDS-DMA window), opt-in
+    //   8  four pixels x three qx columns per thread, 192-thread blocks, one direction per block (round 5; see its header)
     //   7  ten unit waves + six gather waves per 1 024-thread block: the default for maps of up to 2 048 pixels (levels 6, 7 of a
     //      full-HD triplet: 0.043 / 0.031 ms against 0.050 / 0.038 of variant 5)
     const bool win_ok = p.w <= 4096 && p.h <= 4096;
@@ -864,10 +1100,10 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     // instantiations are bit-identical anyway): the sixteen-wave unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet:
     // 0.043 / 0.031 ms against 0.060 / 0.081 of the block-per-tile kernels at batch 16), else by the launch size
 #if !B2F_EXPERIMENTS
-    if (p.variant == 2 || p.variant == 4 || p.variant == 6) p.variant = 3;     // experiment kernels (tools/experiments): not in this build
+    if (p.variant == 2 || p.variant == 4 || p.variant == 6 || p.variant == 8) p.variant = 3;     // experiment kernels (tools/experiments): not in this build
 #endif
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
-                  : (p.ablate ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 7 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+                  : (p.ablate && p.variant < 0 ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 7 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
     if ((variant == 5 || variant == 6 || variant == 7) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
     if (variant == 7) return launch_warp_costvol_gw(p, s);
@@ -879,6 +1115,12 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     } else if (variant == 2) {
         if (pow2) hipLaunchKernelGGL((warp_costvol_2px_kernel<true, 2>), g2, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((warp_costvol_2px_kernel<false, 2>), g2, dim3(256), 0, s, p);
+    } else
+#endif
+#if B2F_EXPERIMENTS
+    if (variant == 8) {
+        if (pow2) hipLaunchKernelGGL((warp_costvol_4px_kernel<true>), dim3(2 * g2.x), dim3(192), 0, s, p);
+        else hipLaunchKernelGGL((warp_costvol_4px_kernel<false>), dim3(2 * g2.x), dim3(192), 0, s, p);
     } else
 #endif
     if (variant == 3) {

@@ -196,12 +196,12 @@ def test_conv3x3_transpose_detecting(hard):
         np.testing.assert_allclose(got, O.conv3x3(x, wt, np.zeros(68, np.float32), 1, False), rtol=0, atol=2e-5)
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7], ids=["corr-regular", "corr-latency", "corr-two-pixel", "corr-two-pixel-one-direction", "corr-window-staged", "corr-unit", "corr-roles", "corr-sixteen-waves"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7, 8], ids=["corr-regular", "corr-latency", "corr-two-pixel", "corr-two-pixel-one-direction", "corr-window-staged", "corr-unit", "corr-roles", "corr-sixteen-waves", "corr-four-pixel"])
 def corr_variant(request, hard):
     """Every instantiation of the warp + cost-volume kernel (the launcher would pick by map / launch size; variants 5 and 6, the
     persistent unit kernel and its role-specialised form, serve channel counts that are multiples of 16 and hand the others to
     variant 3).  Variants 2, 4, 6 are experiments (tools/experiments): they run with the experiments build only."""
-    if request.param in (2, 4, 6):
+    if request.param in (2, 4, 6, 8):
         _need_experiments(hard)
     with hard.options(corr_variant=request.param):
         yield request.param
@@ -259,13 +259,13 @@ def test_warp_costvol_fused(hard, corr_variant, C, h, w, k):
 @pytest.mark.parametrize("C,B,h,w,k,scale", [(32, 3, 145, 456, 0.3125, 1.0), (64, 2, 70, 130, 5.0, 8.0), (96, 2, 33, 65, 2.5, 0.1), (192, 3, 16, 30, 0.625, 1.0),
                                               (128, 1, 9, 17, 1.25, 8.0), (48, 2, 24, 40, 2.5, 1.0), (16, 1, 1, 2, 1.25, 0.0),
                                               (32, 2, 60, 200, 0.625, -1.0), (64, 1, 40, 90, 1.25, -1.0)])
-@pytest.mark.parametrize("variant", [5, 6, 7])
+@pytest.mark.parametrize("variant", [5, 6, 7, 8])
 def test_warp_costvol_unit_kernel_bit_identical(hard, variant, C, B, h, w, k, scale):
     """The persistent unit kernel (corr_variant 5: many tile-directions per block, 16-channel stages, ragged tiles, flows through
     the border clamp, no flow at all), its sixteen-wave form (7: ten unit waves + six gather waves) and its role-specialised form (6: FMA waves / gather waves, source window by LDS-DMA where a
     tile-direction's taps fit it -- scale -1: a translation + small noise, the smooth case that takes the window; white-noise flows
     take its gather fallback) compute the bits of the two-pixel kernel (variant 3) -- same operations in the same order."""
-    if variant == 6:
+    if variant in (6, 8):
         _need_experiments(hard)
     r = _rng(C * 31 + h)
     ref = r.standard_normal((B, C, h, w), dtype=np.float32)
