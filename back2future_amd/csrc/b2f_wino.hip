@@ -31,7 +31,7 @@
 // 4x4 tile (xi = 4w .. 4w+3, all N tiles: 4*NTV accumulators).  Per 8-channel chunk and wave:
 // 4 A operands from LDS, 4*NTV B operands straight from global in two halves (xi pair 0/1 is
 // fetched while pair 2/3 multiplies and vice versa), 16*NTV MFMAs.
-//   raw  [2 buf][2 k4][256 slots] float4   input patch with halo (10 x 18 pixels used)
+//   raw  [2 buf][2 k4][even | odd columns][10 rows][12] float4   input patch with halo (10 x 18 pixels), see RAW_* below
 //   V    [2 buf][16 xi][2 k4][32 tiles] float4   transformed input (A operand)
 // Output: the first half of A^T M A (along b) happens in registers because a wave holds a whole
 // row a; LDS only carries T[a][j][tile][co] (8 instead of 16 planes, 72 KB for NT = 2).
@@ -49,9 +49,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace wino {
 constexpr int TH = 8, TW = 16;
 constexpr int PH = TH + 2, PW = TW + 2;
-constexpr int RAW_P = 256;             // float4 per k4 plane: 10*18 = 180 pixels + dummy slots, so that every one
-                                       // of the 2 x 256 staging items has its own slot
-constexpr int RAW_F4 = 2 * RAW_P;
+// Raw patch in LDS (round 5: conflict-free; the row-major [k4][pixel] planes of rounds 1-4 gave 2-way conflicts on every staging
+// write -- the two k4 planes of a pixel 4 096 bytes apart -- and on every transform read -- the second tile row of a 16-lane group
+// 576 bytes behind the first --: 52 % of the kernel's LDS cycles, profiles/r04_sq_counters.json).  Even and odd patch columns
+// apart: a tile's four columns 2 tx .. 2 tx + 3 are E[tx], O[tx], E[tx + 1], O[tx + 1], so the eight tiles of a tile row read 128
+// contiguous bytes and the next tile row (two patch rows = 2 x 12 float4 = 384 bytes on) the other half of the banks; a 16-lane
+// group of the staging write (8 consecutive pixels x 2 k4) lands in four 64-byte runs that tile 256 bytes (RAW_Q = 4, RAW_S = 8 mod 16).
+constexpr int RAW_ROW = 12;            // float4 per half row (9 used)
+constexpr int RAW_Q = 132;             // odd-column plane (>= 10 * 12, = 4 mod 16)
+constexpr int RAW_S = 264;             // k4 = 1 plane (>= RAW_Q + 120, = 8 mod 16)
+constexpr int RAW_F4 = 2 * RAW_S;
 constexpr int V_F4 = 16 * 2 * 32;
 constexpr int A_F4 = 2 * PH * PW;      // 360 (pixel, k4) items per chunk
 constexpr int lds_bytes(int nt)
@@ -131,11 +138,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned g = a_ok[i] ? (unsigned)(gy * p.W + gx) : 0u;
         a_off0[i] = (g * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
         a_off1[i] = (g * (unsigned)p.seg[p.nseg > 1 ? 1 : 0].pix_stride + (tid & 1) * 4) * 4u;
-        a_slot[i] = (tid & 1) * RAW_P + pix;
+        a_slot[i] = idx < A_F4 ? (tid & 1) * RAW_S + (px & 1) * RAW_Q + py * RAW_ROW + (px >> 1) : 0;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        if (!a_ok[i]) { Rb[a_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; Rb[RAW_F4 + a_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (!a_ok[i] && tid + i * 256 < A_F4) { Rb[a_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; Rb[RAW_F4 + a_slot[i]] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
     const char *wsrc = reinterpret_cast<const char *>(p.wpk) + (size_t)nb * nchunks * U_F4 * 16;
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t_r1 = (t_a == 3) ? 3 : 2;
     const float t_tau = (t_a == 1) ? 1.f : -1.f;
     const f32x4 t_tau4 = {t_tau, t_tau, t_tau, t_tau};
-    const int t_src0 = t_k4 * RAW_P + (2 * (t_tile >> 3) + t_r0) * PW + 2 * (t_tile & 7);
-    const int t_src1 = t_k4 * RAW_P + (2 * (t_tile >> 3) + t_r1) * PW + 2 * (t_tile & 7);
+    const int t_src0 = t_k4 * RAW_S + (2 * (t_tile >> 3) + t_r0) * RAW_ROW + (t_tile & 7);   // column 2 tx + j: + (j & 1) * RAW_Q + (j >> 1)
+    const int t_src1 = t_k4 * RAW_S + (2 * (t_tile >> 3) + t_r1) * RAW_ROW + (t_tile & 7);
     const int t_dst = (t_a * 4 * 2 + t_k4) * 32 + t_tile;   // float4 index of V[xi = 4a][k4][t]; xi+1 -> +64
 #define W_TRANSFORM(v_, s0_, s1_)                                                                   \
     do {                                                                                            \
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         f32x4 s0[4], s1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s0[j] = Rb[t_src0 + j]; s1[j] = Rb[t_src1 + j]; }
+        for (int j = 0; j < 4; ++j) { s0[j] = Rb[t_src0 + (j & 1) * RAW_Q + (j >> 1)]; s1[j] = Rb[t_src1 + (j & 1) * RAW_Q + (j >> 1)]; }
         f32x4 *v = Vb + t_dst;
         W_TRANSFORM(v, s0, s1);
     }
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const f32x4 *r = Rb + ((c + 1) & 1) * RAW_F4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { tr0[j] = r[t_src0 + j]; tr1[j] = r[t_src1 + j]; }
+            for (int j = 0; j < 4; ++j) { tr0[j] = r[t_src0 + (j & 1) * RAW_Q + (j >> 1)]; tr1[j] = r[t_src1 + (j & 1) * RAW_Q + (j >> 1)]; }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 8)) {
