@@ -432,7 +432,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     if (mode == 0 && stride == 2 && c->bf16_conv && c->s2_loader && p.w_off7 && (c->s2_loader >= 2 || p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0) >= 8)) {
         L.wpk_s2b = c->wpk_dev + p.w_off7; L.bias_s2b = c->wpk_dev + p.b_off7;
         s2l = s2b_supported(L);
-        if (s2l) bf6 = false;
+        if (s2l) { bf6 = false; L.nsplit = c->s2_tile_groups ? 0 : -1; }
     }
     // wino1d = 1: the n-blocks with more than 32 real outputs on the 1-D Winograd bf16 kernel, a last block of <= 32 outputs on the
     // F(4x4) single-N-tile kernel (half the bf16 kernel's MFMAs would multiply zero padding); 2: every n-block
@@ -846,6 +846,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
         c->s2_loader = (int)env_int("B2F_S2_LOADER", c->s2_loader);
+        c->s2_tile_groups = (int)env_int("B2F_S2_TILE_GROUPS", c->s2_tile_groups);
 #if B2F_EXPERIMENTS
         c->wino4_split = (int)env_int("B2F_WINO4_SPLIT", c->wino4_split);
         c->wino4_hybrid = (int)env_int("B2F_WINO4_HYBRID", c->wino4_hybrid);
@@ -1014,11 +1015,11 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         drop_graphs(c);
         (key[0] == 's' ? c->s2_tiles_per_block : c->wino4_persistent) = value;
     }
-    else if (!strcmp(key, "s2_loader")) {
+    else if (!strcmp(key, "s2_loader") || !strcmp(key, "s2_tile_groups")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
-        c->s2_loader = value;
+        (key[3] == 'l' ? c->s2_loader : c->s2_tile_groups) = value;
     }
     else if (!strcmp(key, "wino_split_pixels")) {
         HIPCHK(hipSetDevice(c->device));
@@ -1063,6 +1064,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "experiments") *value = B2F_EXPERIMENTS;
     else if (k == "wino1d") *value = c->wino1d;
     else if (k == "s2_loader") *value = c->s2_loader;
+    else if (k == "s2_tile_groups") *value = c->s2_tile_groups;
     else if (k == "wino4_split") *value = c->wino4_split;
     else if (k == "wino4_hybrid") *value = c->wino4_hybrid;
     else if (k == "wino2_split") *value = c->wino2_split;
@@ -1493,6 +1495,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(hipMemcpy(db7.p, b7.data(), b7.size() * sizeof(float), hipMemcpyHostToDevice));
         L.wpk_s2b = dw7.p; L.bias_s2b = db7.p;
         s2l_op = s2b_supported(L);
+        if (s2l_op) L.nsplit = c->s2_tile_groups ? 0 : -1;
     }
     DevBuf dw6, db6;
     bool w1d_op = false;

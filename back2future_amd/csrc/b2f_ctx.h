@@ -249,6 +249,7 @@ struct b2f_ctx {
     int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
                                    // Winograd F(4,3) on the bf16 matrix pipe with exactly split fp32 operands, loader / consumer persistent blocks
                                    // (b2f_w1b.hip); 0 = the fp32-MFMA F(4x4) kernel of rounds 1-4 (b2f_wino4.hip)
+    int s2_tile_groups = 1;        // ... launches that cannot fill the chip: one output tile per block (conv3x3_s2b<1, 1>, ConvLaunch::nsplit); same bits
     int s2_loader = 1;             // stride-2 layers on the bf16 pipe (bf16_conv >= 1): 1 = those of at least 64 input channels on the loader / consumer kernel
                                    // that computes all outputs of a tile (b2f_s2b.hip), 2 = all of them, 0 = conv3x3_bf6 (b2f_convb.hip)
     int wino4_persistent = 1;      // F(4x4) kernel: 1 = persistent blocks (one per CU, K pipeline continues across tiles), 0 = one tile per block, > 1 = that many persistent blocks (tests)

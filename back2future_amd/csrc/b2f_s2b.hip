@@ -36,9 +36,10 @@ constexpr int VBUF = 4 * VPL;                    // 2 720 slots = 43 520 bytes p
 constexpr int NRAW = PR * PC * 2;                // 1 122 raw slots: [row][column][kh] x 16 bytes
 constexpr int NPIECE = (NRAW + 63) / 64;         // 18 DMA pieces of 1 KB
 constexpr int RAWBUF = NPIECE * 64;
-constexpr int NRING = 3;                         // raw-patch buffers: the DMA runs two chunks ahead of the split (a chunk of these layers is short: ~1 700 matrix cycles,
-                                                 // less than an HBM round trip under load)
-constexpr int LDS_BYTES = (2 * VBUF + NRING * RAWBUF) * 16;   // 87 040 + 55 296
+constexpr int NRING = 4;                         // raw-patch buffers: the DMA runs THREE chunks ahead of the split, two whole chunk periods between request and use
+                                                 // (a chunk of these layers is short: ~1 700 matrix cycles, a few hundred in a small launch's one-tile blocks --
+                                                 // less than a memory round trip; three buffers, one period of cover, made a single triplet's coarse levels wait)
+constexpr int LDS_BYTES = (2 * VBUF + NRING * RAWBUF) * 16;   // 87 040 + 73 728 = 160 768
 constexpr int NTAP = 9;
 
 __device__ __forceinline__ unsigned pk(float a, float b)
@@ -67,7 +68,10 @@ struct Item {
     int img, ox0, oy0;
 };
 
-// MTC pixel tiles x one output tile per consumer; consumers = MW = 4 / MTC pixel-tile groups x NW = 4 / MW output tiles (from tile p.nb0 on)
+// MTC pixel tiles x one output tile per consumer; consumers = MW = 4 / MTC pixel-tile groups x NW = 4 / MW output tiles (from tile p.nb0 on).
+// p.nsplit = TG > 0: the grid is TG groups of blocks, group g computes output tiles p.nb0 + NW g ... of ALL pixel tiles (a launch that
+// cannot fill the chip otherwise -- a single triplet's coarse levels: <1, 1> with TG = the layer's tiles makes 4 x the blocks, each
+// with a quarter of the MFMAs in a row; the raw patch is then loaded and split once per group).  Same operations per output: same bits.
 template <int MTC, int NTC>
 __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
 {
@@ -80,15 +84,17 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
 
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const int total = tiles_x * tiles_y * p.nimg;
-    const int G = (int)gridDim.x;
+    const int TG = p.nsplit > 0 ? p.nsplit : 1;
+    const int G = (int)gridDim.x / TG;                              // blocks that share the pixel tiles of one output-tile group
+    const int bx = (int)blockIdx.x % G, tg = (int)blockIdx.x / G;
     const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
-    const int nitems = (total - (int)blockIdx.x + G - 1) / G;
+    const int nitems = (total - bx + G - 1) / G;
     const int nstream = nitems * nchunks;
     const int NT = (p.cout + 31) / 32;                              // 32-output tiles of the layer
 
     auto decode = [&](const int k) {
         Item it;
-        int bid = xcd_remap((int)blockIdx.x + k * G, total);
+        int bid = xcd_remap(bx + k * G, total);
         it.ox0 = (bid % tiles_x) * TW;
         bid /= tiles_x;
         it.oy0 = (bid % tiles_y) * TH;
@@ -161,23 +167,25 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
                 }
             }
         };
-        // The DMA of chunk v + 3 is issued while chunk v + 1 is split: before a barrier that publishes chunk v + 2's raw patch a producer
-        // waits until only its NEWEST batch of pieces (five for producers 0, 1, four for 2, 3) is still in flight.
-#define S2B_LANDED_BARRIER() do { if (pw < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+        // The DMA of chunk v + 4 is issued while chunk v + 1 is split: before a barrier that publishes chunk v + 2's raw patch a producer
+        // waits until only its TWO NEWEST batches of pieces (five each for producers 0, 1, four for 2, 3) are still in flight.
+#define S2B_LANDED_BARRIER() do { if (pw < 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+        static_assert(NRING == 4, "the waits below count two batches in flight");
         request(0);
         S2B_DONE_BARRIER();                                         // P0: raw patch of chunk 0 is in LDS
         request(1);
         request(2);
+        request(3);
         produce(0, 0);
         S2B_LANDED_BARRIER();                                       // A0: V of chunk 0 complete, raw patch of chunk 1 landed
-        int r1 = 1, r3 = 0;                                         // ring slots of chunks v + 1 and v + 3
+        int r1 = 1, r4 = 0;                                         // ring slots of chunks v + 1 and v + 4
         for (int v = 0; v < nstream; ++v) {
-            request(r3);                                            // slot of chunk v: split before B_{v-1}
+            request(r4);                                            // slot of chunk v: split before B_{v-1}
             produce(v + 1, r1);
             S2B_LANDED_BARRIER();                                   // B_v: V of chunk v + 1 complete, raw patch of chunk v + 2 landed
             S2B_BARRIER();                                          // B'_v
             r1 = r1 == NRING - 1 ? 0 : r1 + 1;
-            r3 = r3 == NRING - 1 ? 0 : r3 + 1;
+            r4 = r4 == NRING - 1 ? 0 : r4 + 1;
         }
         return;
     }
@@ -193,12 +201,17 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
 
     static_assert(NTC == 1, "one output tile per consumer (more tiles: more launches, see launch_conv3x3_s2b)");
     f32x16 acc[MTC];
-    u32x4 wa[3], wb[3];
+    // weight windows: a ring over the taps, loaded WLA taps ahead.  Two taps (24 MFMAs) cover the L2 round trip when a consumer has four
+    // pixel tiles; with ONE (the small launches' <1, 1> form: six MFMAs per tap) the consumers waited for every tap's weights -- 3 700 cycles
+    // per chunk for 900 of MFMAs -- so that form looks seven taps ahead (72 registers it has to spare).
+    constexpr int WLA = MTC == 1 ? 7 : 2, WR = MTC == 1 ? 9 : 3;
+    static_assert(NTAP % WR == 0 && WLA < WR, "ring slots are compile-time constants of the tap index");
+    u32x4 wa[WR], wb[WR];
     // Pixel windows in THREE rotating register sets: a set is loaded one tap ahead and was last read a whole tap before that.  A ds_read into a register that a just-issued MFMA still has to read corrupts that MFMA (measured: the hardware
     // does not interlock it and hipcc adds no wait states; wrong outputs in the lanes of the first LDS return group) -- so no register
     // is reloaded "right behind the MFMAs that read it" here, and consecutive MFMAs never share an accumulator.
     u32x4 xa[3][MTC], xb[3][MTC];
-    const int tile = nw + p.nb0;                                    // this consumer's tile of 32 outputs
+    const int tile = nw + p.nb0 + (4 / MW) * tg;                    // this consumer's tile of 32 outputs
     const bool active = tile < NT;
     auto load_w = [&](const int slot, const int chunk_off, const int tap) {
         const int so = chunk_off + tap * tap_bytes + min(tile, NT - 1) * 1024;   // a tile past the last one: its accumulators stay unused
@@ -219,8 +232,8 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
     int k = 0, c = 0;
     Item cur = decode(0);
     int w_cur = 0;
-    load_w(0, 0, 0);
-    load_w(1, 0, 1);
+#pragma unroll
+    for (int t = 0; t < WLA; ++t) load_w(t, 0, t);
     zero();
     S2B_BARRIER();                                                  // P0
     S2B_BARRIER();                                                  // A0
@@ -236,8 +249,8 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
 #pragma unroll
         for (int s = 0; s < NTAP; ++s) {
             constexpr int XS[NTAP + 1] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 0};     // register set of tap s (entry 9 = tap 0 of the next chunk): the set loaded during tap s was last read in tap s - 2
-            if (s + 2 < NTAP) load_w((s + 2) % 3, w_cur, s + 2);
-            else load_w((s + 2) % 3, w_nxt, s + 2 - NTAP);
+            if (s + WLA < NTAP) load_w((s + WLA) % WR, w_cur, s + WLA);
+            else load_w((s + WLA) % WR, w_nxt, s + WLA - NTAP);
             if (s == NTAP - 2) S2B_BARRIER();                       // B_v: V of chunk v + 1 is complete
 #pragma unroll
             for (int mt = 0; mt < MTC; ++mt) {                      // the next tap's windows into the set that was read a tap ago
@@ -246,11 +259,11 @@ __global__ __launch_bounds__(512) void conv3x3_s2b(const ConvLaunch p)
             }
             __builtin_amdgcn_sched_barrier(0);                      // the scheduler otherwise sinks every load to its first use
 #pragma unroll
-            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wa[s % 3], xa[XS[s]][mt]);
+            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wa[s % WR], xa[XS[s]][mt]);
 #pragma unroll
-            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wb[s % 3], xa[XS[s]][mt]);
+            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wb[s % WR], xa[XS[s]][mt]);
 #pragma unroll
-            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wa[s % 3], xb[XS[s]][mt]);
+            for (int mt = 0; mt < MTC; ++mt) S2B_MF(acc[mt], wa[s % WR], xb[XS[s]][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         S2B_BARRIER();                                              // B'_v: done reading V of chunk v
@@ -352,6 +365,15 @@ hipError_t launch_conv3x3_s2b(const ConvLaunch &p, hipStream_t s)
     // consumers: two output-tile groups x two pixel-tile groups for <= 2 output tiles, four output tiles (each consumer all four pixel
     // tiles) above; a layer with more tiles takes one launch per four (the patch is then read once per launch: 128 -> 192 only)
     ConvLaunch q = p;
+    q.nsplit = 0;
+    // a launch whose blocks cannot fill the chip (single triplets, the coarse levels): one output tile per block, the four consumers
+    // take one pixel tile each -- NT x the blocks, a quarter of the MFMAs in a row per wave (p.nsplit < 0 switches it off: option s2_tile_groups = 0)
+    if (p.nsplit >= 0 && total * ((NT + 3) / 4) * 2 <= cap && total * NT <= 2 * cap) {
+        const int gp = total * NT <= cap ? total : cap / NT;
+        q.nb0 = 0;
+        q.nsplit = NT;
+        return s2b_launch_t<1, 1>(q, gp * NT, s);
+    }
     if (NT <= 2) { q.nb0 = 0; return s2b_launch_t<2, 1>(q, grid, s); }
     for (int t0 = 0; t0 < NT; t0 += 4) {
         q.nb0 = t0;

@@ -1136,7 +1136,10 @@ def test_stride2_loader_consumer_kernel(hard, B, ci, co, h, w, scale, blocks):
     with hard.options(bf16_conv=1, s2_loader=2, wino4_persistent=blocks):
         got = ops.conv3x3(hard, x, wt, b, 2, True)
     with hard.options(bf16_conv=1, s2_loader=2, wino4_persistent=1):
-        got1 = ops.conv3x3(hard, x, wt, b, 2, True)
+        got1 = ops.conv3x3(hard, x, wt, b, 2, True)                  # small launches: one output tile per block (s2_tile_groups, the default)
+    with hard.options(bf16_conv=1, s2_loader=2, wino4_persistent=1, s2_tile_groups=0):
+        got0 = ops.conv3x3(hard, x, wt, b, 2, True)                  # always all outputs of a tile per block
+    assert np.array_equal(got1, got0)
     np.testing.assert_allclose(got, O.conv3x3(x, wt, b, 2, True), rtol=2e-5, atol=2e-5 * scale)
     es, ef = np.abs(got - exp), np.abs(f32 - exp)
     assert es.max() <= 1e-4 * scale and es.max() <= 1.5 * ef.max() + 1e-6 * scale
