@@ -172,6 +172,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             for (int k = 0; k < p.chunks[0] * kCK; ++k) m.push_back(k < d.ci ? k : -1);
         }
         const int chunks = p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0);
+        total = (total + 3) & ~(size_t)3;   // every packing starts 16-byte aligned (conv_narrow2 reads its weights as float4)
         p.w_off = total;
         total += p.wino == 4 ? wino4_wpk_floats(chunks, p.nblk) : p.wino == 1 ? narrow2_wpk_floats(chunks)
                  : p.wino == 3 ? c16_wpk_floats() : p.wino == 5 ? c16s2_wpk_floats() : p.wino == 2 ? wino_wpk_floats(chunks, p.nt, p.nblk)

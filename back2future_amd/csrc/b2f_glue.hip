@@ -327,18 +327,21 @@ hipError_t launch_conv_first(const float *in, int normalize, int B, int H, int W
 // (u, v) resp. the two occlusion logits) -- as a plain VALU kernel: with 2 outputs an MFMA tile would be 94 %
 // padding.  HBM-bound (Ci * 4 B read per pixel).  Block = 256 threads = 16 x 16 pixels; the 18 x 18 patch of up
 // to 32 input channels sits in LDS as [chunk][k4][pixel] float4 (conflict-free b128 reads); weights
-// [chunk][tap][8 ci][2 co] come in as scalar (SGPR) operands; one thread = one pixel, 2 x 9 x Ci fmas.
+// [chunk][tap][8 ci][2 co] are staged in LDS with the patch and read back as broadcasts (rounds 1-4 read them as scalar operands:
+// 36 dependent s_load round trips through a cold scalar cache were ~10 of a launch's ~16 us whatever its size); one thread = one
+// pixel, 2 x 9 x Ci fmas.
 // Chunk-planar in, chunk-planar out (channels 0, 1 of output chunk 0).
+// CPB = input chunks staged per pass: 2 -> 21 KB of LDS, seven blocks per CU: launches that fill the chip; 4 -> 42 KB, the 32-channel
+// input of the decoders' last layer in ONE pass (one memory round trip instead of two): launches of a few hundred blocks at most,
+// where the round trips are all the run time (a single triplet: 6 launches x ~3 us).  Same operations in the same order.
+template <int CPB>
 __global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long img_stride, long chunk_stride, int pix_stride,
                                                            int nchunks, int H, int W, const float *wt, const float *bias,
                                                            float *out, long out_img_stride, int out_pix_stride, int leaky)
 {
     constexpr int T = 16, P = T + 2, NP = P * P;     // 324 patch pixels
-#ifndef B2F_N2_CPB
-#define B2F_N2_CPB 2
-#endif
-    constexpr int CPB = B2F_N2_CPB;                  // input chunks staged per pass: 2 -> 21 KB of LDS, seven blocks per CU (4: 42 KB, three)
     __shared__ float4 patch[CPB][2][NP + 4];
+    __shared__ float4 wsh[CPB * 36];                 // [chunk][tap][ci pair][ci0.co0 ci0.co1 ci1.co0 ci1.co1]
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
     int bid = blockIdx.x;
     const int tx_i = bid % tiles_x;
@@ -367,30 +370,33 @@ __global__ __launch_bounds__(256) void conv_narrow2_kernel(const float *in, long
             v[k] = *reinterpret_cast<const float4 *>(src + (size_t)(ok[k] ? c0 + c : 0) * chunk_stride +
                                                      (ok[k] ? (size_t)gy * W + gx : 0) * pix_stride + 4 * k4);
         }
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x < nc * 36) wv = *reinterpret_cast<const float4 *>(wt + (size_t)c0 * (9 * 8 * 2) + 4 * threadIdx.x);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int i = threadIdx.x + k * 256;
             const int c = i / (2 * NP), r = i - c * (2 * NP);
             if (i < nc * 2 * NP) patch[c][r & 1][r >> 1] = ok[k] ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if ((int)threadIdx.x < CPB * 36) wsh[threadIdx.x] = wv;
         __syncthreads();
         for (int c = 0; c < nc; ++c) {
-            const float *w = wt + (size_t)(c0 + c) * (9 * 8 * 2);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int pp = (ty + ky) * P + tx + kx;
                     const float4 lo = patch[c][0][pp], hi = patch[c][1][pp];
-                    const float *wk = w + (ky * 3 + kx) * 16;
-                    a0 = fmaf(lo.x, wk[0], a0);  a1 = fmaf(lo.x, wk[1], a1);
-                    a0 = fmaf(lo.y, wk[2], a0);  a1 = fmaf(lo.y, wk[3], a1);
-                    a0 = fmaf(lo.z, wk[4], a0);  a1 = fmaf(lo.z, wk[5], a1);
-                    a0 = fmaf(lo.w, wk[6], a0);  a1 = fmaf(lo.w, wk[7], a1);
-                    a0 = fmaf(hi.x, wk[8], a0);  a1 = fmaf(hi.x, wk[9], a1);
-                    a0 = fmaf(hi.y, wk[10], a0); a1 = fmaf(hi.y, wk[11], a1);
-                    a0 = fmaf(hi.z, wk[12], a0); a1 = fmaf(hi.z, wk[13], a1);
-                    a0 = fmaf(hi.w, wk[14], a0); a1 = fmaf(hi.w, wk[15], a1);
+                    const float4 *wk = wsh + (c * 9 + ky * 3 + kx) * 4;
+                    const float4 w0 = wk[0], w1 = wk[1], w2 = wk[2], w3 = wk[3];
+                    a0 = fmaf(lo.x, w0.x, a0);  a1 = fmaf(lo.x, w0.y, a1);
+                    a0 = fmaf(lo.y, w0.z, a0);  a1 = fmaf(lo.y, w0.w, a1);
+                    a0 = fmaf(lo.z, w1.x, a0);  a1 = fmaf(lo.z, w1.y, a1);
+                    a0 = fmaf(lo.w, w1.z, a0);  a1 = fmaf(lo.w, w1.w, a1);
+                    a0 = fmaf(hi.x, w2.x, a0);  a1 = fmaf(hi.x, w2.y, a1);
+                    a0 = fmaf(hi.y, w2.z, a0);  a1 = fmaf(hi.y, w2.w, a1);
+                    a0 = fmaf(hi.z, w3.x, a0);  a1 = fmaf(hi.z, w3.y, a1);
+                    a0 = fmaf(hi.w, w3.z, a0);  a1 = fmaf(hi.w, w3.w, a1);
                 }
         }
     }
@@ -405,9 +411,14 @@ hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s)
 {
     if (p.stride != 1 || p.cout != 2 || p.nseg != 1 || (p.seg[0].pix_stride & 3) || (p.out_pix_stride & 1)) return hipErrorInvalidValue;
     const int tiles = ((p.W + 15) / 16) * ((p.H + 15) / 16);
-    hipLaunchKernelGGL(conv_narrow2_kernel, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p.seg[0].ptr, p.seg[0].img_stride,
-                       p.seg[0].chunk_stride, p.seg[0].pix_stride, p.seg[0].nchunks, p.H, p.W, p.wpk, p.bias, p.out,
-                       p.out_img_stride, p.out_pix_stride, p.leaky);
+    if ((long)tiles * p.nimg <= 768 && p.seg[0].nchunks > 2)   // at most three blocks per CU anyway
+        hipLaunchKernelGGL(conv_narrow2_kernel<4>, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p.seg[0].ptr, p.seg[0].img_stride,
+                           p.seg[0].chunk_stride, p.seg[0].pix_stride, p.seg[0].nchunks, p.H, p.W, p.wpk, p.bias, p.out,
+                           p.out_img_stride, p.out_pix_stride, p.leaky);
+    else
+        hipLaunchKernelGGL(conv_narrow2_kernel<2>, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p.seg[0].ptr, p.seg[0].img_stride,
+                           p.seg[0].chunk_stride, p.seg[0].pix_stride, p.seg[0].nchunks, p.H, p.W, p.wpk, p.bias, p.out,
+                           p.out_img_stride, p.out_pix_stride, p.leaky);
     return hipGetLastError();
 }
 
