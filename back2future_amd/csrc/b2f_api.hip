@@ -415,6 +415,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     L.leaky = leaky;
     L.tiles_per_block = c->s2_tiles_per_block;
     L.w4_persist = c->wino4_persistent;
+    L.w8 = c->wino8;
 #if B2F_EXPERIMENTS
     L.wpk_split = (mode == 4 && (c->wino4_split || c->wino4_hybrid) && p.w_off3) ? c->wpk_dev + p.w_off3 : nullptr;
     L.w4_hybrid = c->wino4_hybrid;
@@ -836,6 +837,7 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         };
         c->wino4_min_pixels = (int)env_int("B2F_WINO4_MIN_PIXELS", c->wino4_min_pixels);
         c->wino_split_pixels = (int)env_int("B2F_WINO_SPLIT_PIXELS", c->wino_split_pixels);
+        c->wino8 = (int)env_int("B2F_WINO8", c->wino8);
         c->adaptive_kernels = (int)env_int("B2F_ADAPTIVE_KERNELS", c->adaptive_kernels);
         c->corr_variant = (int)env_int("B2F_CORR_VARIANT", env_int("B2F_CORR_LAT", c->corr_variant));   // B2F_CORR_LAT: the round-1 name
         c->op_wino_split = (int)env_int("B2F_OP_WINO_SPLIT", c->op_wino_split);
@@ -1022,11 +1024,11 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         drop_graphs(c);
         (key[3] == 'l' ? c->s2_loader : c->s2_tile_groups) = value;
     }
-    else if (!strcmp(key, "wino_split_pixels")) {
+    else if (!strcmp(key, "wino_split_pixels") || !strcmp(key, "wino8")) {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipDeviceSynchronize());
         drop_graphs(c);
-        c->wino_split_pixels = value;
+        (key[4] == '8' ? c->wino8 : c->wino_split_pixels) = value;
     }
     else if (!strcmp(key, "wino4_min_pixels") || !strcmp(key, "adaptive_kernels")) {
         // a different kernel mix: captured graphs hold the old one
@@ -1074,6 +1076,7 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "bf16_conv_min_pixels") *value = c->bf16_conv_min_pixels;
     else if (k == "wino4_min_pixels") *value = c->wino4_min_pixels;
     else if (k == "wino_split_pixels") *value = c->wino_split_pixels;
+    else if (k == "wino8") *value = c->wino8;
     else if (k == "adaptive_kernels") *value = c->adaptive_kernels;
     else if (k == "corr_variant") *value = c->corr_variant;
     else if (k == "corr_ablate") *value = c->corr_ablate;
@@ -1473,6 +1476,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     L.nsplit = op_split ? 1 : 0;
     L.nb0 = 0; L.trace = nullptr;
     L.w4_persist = c->wino4_persistent;
+    L.w8 = c->wino8;
     L.wpk_split = dws.p;
     L.w4_hybrid = c->wino4_hybrid;
     L.bf16_direct = c->bf16_direct;

@@ -1098,12 +1098,15 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
     const bool win_ok = p.w <= 4096 && p.h <= 4096;
     // default: by the map size for the small maps (so that a triplet's kernel does not depend on the batch it is computed in; the
     // instantiations are bit-identical anyway): the sixteen-wave unit kernel up to 2 048 pixels (levels 6, 7 of a full-HD triplet:
-    // 0.043 / 0.031 ms against 0.060 / 0.081 of the block-per-tile kernels at batch 16), else by the launch size
+    // 0.043 / 0.031 ms against 0.060 / 0.081 of the block-per-tile kernels at batch 16), else by the launch size: the two-pixel
+    // kernel needs about one full round of its 1 024 resident blocks (a single triplet's 256 x 480 level has 960), anything smaller
+    // also runs the sixteen-wave unit kernel (round 5, single triplet at 3x1024x1920: levels 4 / 5 0.027 / 0.020 ms against
+    // 0.037 / 0.046 of the one-pixel kernels, level 3 0.046 on the two-pixel kernel against 0.060: 0.196 -> 0.145 ms per call)
 #if !B2F_EXPERIMENTS
     if (p.variant == 2 || p.variant == 4 || p.variant == 6 || p.variant == 8) p.variant = 3;     // experiment kernels (tools/experiments): not in this build
 #endif
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
-                  : (p.ablate && p.variant < 0 ? 0 : (p.h * p.w <= 2048 && warp_costvol_unit_supported(p)) ? 7 : g2.x >= 512 ? 3 : grid.x <= 512 ? 1 : 0);
+                  : (p.ablate ? 0 : ((p.h * p.w <= 2048 || 2 * g2.x < 960) && warp_costvol_unit_supported(p)) ? 7 : 2 * g2.x >= 960 ? 3 : grid.x <= 512 ? 1 : 0);
     if ((variant == 5 || variant == 6 || variant == 7) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
     if (variant == 7) return launch_warp_costvol_gw(p, s);

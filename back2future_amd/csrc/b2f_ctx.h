@@ -222,6 +222,7 @@ struct b2f_ctx {
     int host_graph = 1;   // b2f_compute_flow*: replay hipGraphs for repeated (shape, sub-batch) combinations
     // kernel selection and pipeline tuning (b2f_set_option; seeded once from the environment in b2f_init, never read
     // from it on the hot path)
+    int wino8 = 1;                 // F(2x2) one-N-tile launches of at most one block per CU run the eight-wave form (conv3x3_wino8; same bits)
     int wino_split_pixels = 512;   // F(2x2) launches on maps of at most this many pixels run one block per 32-output N tile (same bits;
                                    // level 7 of a full-HD triplet: 64 tiles per launch at batch 16 -- 0.25 -> 0.20 ms for its six layers)
     int wino4_min_pixels = 4096;   // F(4x4) for maps of at least this many pixels, F(2x2) below: depends on the map size

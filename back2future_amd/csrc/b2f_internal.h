@@ -59,6 +59,7 @@ struct ConvLaunch {
     long long *trace;   // profiling builds only (B2F_WINO_TRACE), nullptr otherwise
     int nb0;            // first n-block of this launch (Winograd kernel: a layer may be split over two launches)
     int nsplit;         // F(2x2) kernel: 1 = one block per 32-output N tile of the 64-wide packing (more, lighter blocks for small launches)
+    int w8 = 1;                // F(2x2) kernel: one-N-tile launches of at most one block per CU run the eight-wave form (same bits)
     int w4_persist = 1;        // F(4x4) kernel: persistent blocks (one per CU) when the launch has at least two tiles per CU
     int tiles_per_block = 0;   // direct kernel: consecutive tiles a block chains into one (tile, chunk) pipeline; 0 = launcher's choice
     int w4_hybrid = 0;                 // F(4x4) persistent two-N-tile kernel: xi steps per wave that run on the bf16 pipe with split operands (0 = none)

@@ -352,6 +352,220 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ======================================================================================================
+// Eight-wave form of the one-N-tile instantiations (round 5): for launches of at most one block per CU -- a single triplet's
+// coarse levels, where a launch is as long as ONE block's K loop and that loop is its 16 fp32 MFMAs per wave and chunk
+// (1 024 cycles).  512 threads: wave w = (row a = w & 3 of the transformed tile, xi pair q = w >> 2) multiplies xi = 4 a + 2 q,
+// + 1 only (8 MFMAs per chunk), the input transform is split the same way (thread = (tile, a, k4, pair): three of the four patch
+// columns, two V values), staging is one item per thread.  All 16 M planes go through LDS (80 KB, one block per CU) and the
+// output stage forms A^T M A from them with the four-wave kernel's operations in its order: same bits.
+template <int NT>
+__global__ __launch_bounds__(512) void conv3x3_wino8(const ConvLaunch p)
+{
+    using namespace wino;
+    constexpr int NB = NT * 32;
+    constexpr int U_F4 = 16 * 2 * NB;
+    constexpr int XS8 = 32 + 8;              // floats per (plane, tile) row of the output exchange
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *Vb = reinterpret_cast<f32x4 *>(smem);                 // [2][V_F4]
+    f32x4 *Rb = Vb + 2 * V_F4;                                    // [2][RAW_F4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int w_a = wave & 3, w_q = wave >> 2;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nbx = bid % p.nblk;
+    const int nt0 = NT == 2 ? (nbx & p.nsplit) : 0;
+    const int nb = (nbx >> (NT == 2 ? p.nsplit : 0)) + p.nb0;
+    bid /= p.nblk;
+    const int tx_i = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty_i = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int ox0 = tx_i * TW, oy0 = ty_i * TH;
+    const int ix0 = ox0 - 1, iy0 = oy0 - 1;
+
+    // ---- staging: item tid -> (pixel tid >> 1, k4 = tid & 1) ----
+    unsigned a_off0, a_off1;
+    int a_slot;
+    bool a_ok;
+    {
+        const int pix = tid >> 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = iy0 + py, gx = ix0 + px;
+        a_ok = (tid < A_F4) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const unsigned g = a_ok ? (unsigned)(gy * p.W + gx) : 0u;
+        a_off0 = (g * (unsigned)p.seg[0].pix_stride + (tid & 1) * 4) * 4u;
+        a_off1 = (g * (unsigned)p.seg[p.nseg > 1 ? 1 : 0].pix_stride + (tid & 1) * 4) * 4u;
+        a_slot = tid < A_F4 ? (tid & 1) * RAW_S + (px & 1) * RAW_Q + py * RAW_ROW + (px >> 1) : 0;
+        if (!a_ok && tid < A_F4) { Rb[a_slot] = f32x4{0.f, 0.f, 0.f, 0.f}; Rb[RAW_F4 + a_slot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const int nchunks = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const char *wsrc = reinterpret_cast<const char *>(p.wpk) + (size_t)nb * nchunks * U_F4 * 16;
+    const __amdgpu_buffer_rsrc_t r_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[0].ptr + (size_t)img * p.seg[0].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.seg[1].ptr + (size_t)img * p.seg[1].img_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wsrc), 0, 0x7fffffff, 0x00020000);
+    auto load_raw = [&](const int c) {
+        const bool s1 = c >= p.seg[0].nchunks;
+        const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;
+        const int so = (int)((s1 ? c - p.seg[0].nchunks : c) * cstr * 4);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)(s1 ? a_off1 : a_off0), so, 0));
+    };
+    // B operands of this wave's xi pair: lane (m, half) loads U[xi][k4 = half][nt0 * 32 + m]
+    const unsigned b_off = (((4 * w_a + 2 * w_q) * 2 + half) * NB + nt0 * 32 + m) * 16u;
+    auto load_u = [&](f32x4 (&dst)[2], const int c) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            dst[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, c * (U_F4 * 16) + x * 2 * NB * 16, 0));
+    };
+    // input transform: thread = (tile, row a, k4, pair bh): w = d[r0] + tau d[r1] of the columns bh .. bh + 2, then
+    //   bh = 0: V[4a] = w0 - w2, V[4a + 1] = w1 + w2      bh = 1: V[4a + 2] = w2 - w1, V[4a + 3] = w1 - w3
+    const int t_tile = tid & 31, t_a = (tid >> 5) & 3, t_k4 = (tid >> 7) & 1, t_bh = w_q;
+    const int t_r0 = (t_a == 0) ? 0 : 1;
+    const int t_r1 = (t_a == 3) ? 3 : 2;
+    const float t_tau = (t_a == 1) ? 1.f : -1.f;
+    const f32x4 t_tau4 = {t_tau, t_tau, t_tau, t_tau};
+    const int t_src0 = t_k4 * RAW_S + (2 * (t_tile >> 3) + t_r0) * RAW_ROW + (t_tile & 7);
+    const int t_src1 = t_k4 * RAW_S + (2 * (t_tile >> 3) + t_r1) * RAW_ROW + (t_tile & 7);
+    const int t_dst = ((4 * t_a + 2 * t_bh) * 2 + t_k4) * 32 + t_tile;   // second value: + 64
+    // patch column bh + i of the tile: slot + ((bh + i) & 1) * RAW_Q + ((bh + i) >> 1)
+    const int t_c0 = t_bh ? RAW_Q : 0, t_c1 = t_bh ? 1 : RAW_Q, t_c2 = t_bh ? RAW_Q + 1 : 1;
+    auto read_cols = [&](const f32x4 *r, f32x4 (&s0)[3], f32x4 (&s1)[3]) {
+        s0[0] = r[t_src0 + t_c0]; s0[1] = r[t_src0 + t_c1]; s0[2] = r[t_src0 + t_c2];
+        s1[0] = r[t_src1 + t_c0]; s1[1] = r[t_src1 + t_c1]; s1[2] = r[t_src1 + t_c2];
+    };
+    auto transform = [&](f32x4 *v, const f32x4 (&s0)[3], const f32x4 (&s1)[3]) {
+        f32x4 w[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[j] = __builtin_elementwise_fma(t_tau4, s1[j], s0[j]);
+        if (t_bh == 0) { v[0] = w[0] - w[2]; v[64] = w[1] + w[2]; }
+        else { v[0] = w[1] - w[0]; v[64] = w[0] - w[2]; }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    const int a_off = ((4 * w_a + 2 * w_q) * 2 + half) * 32 + m;          // V[xi][k4 = half][tile m]; xi + 1 -> + 64
+    f32x4 b0[2], b1[2];
+
+    // ---- prologue: raw(0), raw(1), B(0) in flight together ----
+    {
+        const f32x4 r1 = load_raw(min(1, nchunks - 1));
+        const f32x4 r0 = load_raw(0);
+        load_u(b0, 0);
+        if (a_ok) { Rb[a_slot] = r0; Rb[RAW_F4 + a_slot] = r1; }
+    }
+    __syncthreads();
+    {
+        f32x4 s0[3], s1[3];
+        read_cols(Rb, s0, s1);
+        transform(Vb + t_dst, s0, s1);
+    }
+    __syncthreads();
+
+    // chunk c: [issue B(c + 1), raw(c + 2), the LDS reads] [8 MFMAs] [transform of chunk c + 1] [raw(c + 2) -> LDS] barrier
+    auto iter = [&](const int c, const f32x4 (&bc)[2], f32x4 (&bn)[2]) __attribute__((always_inline)) {
+        load_u(bn, min(c + 1, nchunks - 1));
+        const f32x4 ra = load_raw(min(c + 2, nchunks - 1));
+        const f32x4 *Vc = Vb + (c & 1) * V_F4 + a_off;
+        f32x4 av[2], s0[3], s1[3];
+        av[0] = Vc[0]; av[1] = Vc[64];
+        read_cols(Rb + ((c + 1) & 1) * RAW_F4, s0, s1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        transform(Vb + ((c + 1) & 1) * V_F4 + t_dst, s0, s1);
+        if (a_ok) Rb[(c & 1) * RAW_F4 + a_slot] = ra;
+        __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        iter(c, b0, b1);
+        if (c + 1 < nchunks) iter(c + 1, b1, b0);
+    }
+
+    // ---- output: all 16 planes M[a][b] through LDS, then T[a][j] and Y as in the four-wave kernel ----
+    float *X = reinterpret_cast<float *>(smem);   // staging buffers are dead (barrier at loop end)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (r & 3) + 8 * (r >> 2) + 4 * half;
+            X[((4 * w_a + 2 * w_q + x) * 32 + t) * XS8 + m] = acc[x][r];
+        }
+    __syncthreads();
+    if (tid < 256) {
+        float *ob = p.out + (size_t)img * p.out_img_stride;
+        const bool vec_ok = ((p.out_pix_stride | (int)p.out_chunk_stride) & 3) == 0;
+        const int o_cq = tid & 7, o_t = tid >> 3;
+        const int co0 = nb * NB + nt0 * 32 + 4 * o_cq;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + co0);
+        f32x4 mm[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 mb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mb[b] = *reinterpret_cast<const f32x4 *>(X + ((a * 4 + b) * 32 + o_t) * XS8 + 4 * o_cq);
+            mm[a][0] = mb[0] + mb[1] + mb[2];
+            mm[a][1] = mb[1] - mb[2] - mb[3];
+        }
+        const int oy = oy0 + 2 * (o_t >> 3), ox = ox0 + 2 * (o_t & 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = bias + (i == 0 ? (mm[0][j] + mm[1][j] + mm[2][j]) : (mm[1][j] - mm[2][j] - mm[3][j]));
+                if (p.leaky) v = __builtin_elementwise_max(v, 0.2f * v);
+                if (oy + i < p.Ho && ox + j < p.Wo && co0 < p.cout) {
+                    float *dst = ob + (size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + (co0 & 7);
+                    if (vec_ok && co0 + 3 < p.cout) {
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (co0 + e < p.cout)
+                                ob[(size_t)((co0 + e) >> 3) * p.out_chunk_stride + (size_t)((oy + i) * p.Wo + ox + j) * p.out_pix_stride + ((co0 + e) & 7)] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static hipError_t launch_wino8_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
+{
+    using namespace wino;
+    constexpr int stage = 16 * (2 * V_F4 + 2 * RAW_F4), xch = 16 * 32 * (32 + 8) * 4;
+    constexpr int lds = stage > xch ? stage : xch;
+    static bool attr_done_dev[64] = {false};
+    bool &attr_done = attr_done_dev[attr_slot()];
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino8<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvLaunch q = p;
+    q.nb0 = nb0;
+    q.nsplit = NT == 2 ? p.nsplit : 0;
+    q.trace = nullptr;
+    q.nblk = nblk;
+    const int tiles = ((p.Wo + TW - 1) / TW) * ((p.Ho + TH - 1) / TH);
+    hipLaunchKernelGGL((conv3x3_wino8<NT>), dim3((unsigned)(tiles * p.nimg * nblk)), dim3(512), lds, s, q);
+    return hipGetLastError();
+}
+
 template <int NT, int NTV>
 static hipError_t launch_wino_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
 {
@@ -409,15 +623,21 @@ hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s)
     // 32-bit byte offsets inside one (image, chunk) plane
     for (int i = 0; i < p.nseg; ++i)
         if ((double)p.H * p.W * p.seg[i].pix_stride * 4.0 >= 4294967296.0) return hipErrorInvalidValue;
-    if (p.nt == 1) return launch_wino_t<1, 1>(p, 0, p.nblk, s);
+    // one-N-tile launches of at most one block per CU: the eight-wave form (same bits; p.w8 = 0 switches it off)
+    const long tiles8 = (long)((p.Wo + wino::TW - 1) / wino::TW) * ((p.Ho + wino::TH - 1) / wino::TH) * p.nimg;
+    const bool w8 = p.w8 != 0;
+    if (p.nt == 1) return (w8 && tiles8 * p.nblk <= 256) ? launch_wino8_t<1>(p, 0, p.nblk, s) : launch_wino_t<1, 1>(p, 0, p.nblk, s);
     if (p.nt != 2) return hipErrorInvalidValue;
-    if (p.nsplit) return launch_wino_t<2, 1>(p, 0, (p.cout + 31) / 32, s);   // one block per 32 outputs
+    if (p.nsplit) {   // one block per 32 outputs
+        const int n32 = (p.cout + 31) / 32;
+        return (w8 && tiles8 * n32 <= 256) ? launch_wino8_t<2>(p, 0, n32, s) : launch_wino_t<2, 1>(p, 0, n32, s);
+    }
     // n-blocks whose two N tiles both hold real channels, then the half-empty last one (cout = 96)
     const int nfull = p.cout / 64, part = (p.cout % 64) ? 1 : 0;
     const bool part_full = (p.cout % 64) > 32;
     hipError_t e = hipSuccess;
     if (nfull + (part_full ? 1 : 0) > 0) e = launch_wino_t<2, 2>(p, 0, nfull + (part_full ? 1 : 0), s);
-    if (e == hipSuccess && part && !part_full) e = launch_wino_t<2, 1>(p, nfull, 1, s);
+    if (e == hipSuccess && part && !part_full) e = (w8 && tiles8 <= 256) ? launch_wino8_t<2>(p, nfull, 1, s) : launch_wino_t<2, 1>(p, nfull, 1, s);
     return e;
 }
 

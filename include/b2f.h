@@ -193,7 +193,10 @@ B2F_API int b2f_output_shapes(const b2f_ctx *ctx, int H, int W, int *ch, int *oh
  * 0 .. 7) forces an instantiation of the warp + cost-volume kernel (same bits either way);
  * wino4_persistent (default 1) = F(4x4) launches run as persistent blocks, one per CU
  * (0: one tile per block; same bits either way); s2_tiles_per_block
- * (default 0 = launcher's rule) = tiles a block of the stride-2 kernel chains (same bits).
+ * (default 0 = launcher's rule) = tiles a block of the stride-2 kernel chains (same bits);
+ * wino8 / s2_tile_groups (default 1) = launches that cannot fill the chip (a single triplet's
+ * coarse levels) run the eight-wave F(2x2) kernel / one 32-output tile per stride-2 block
+ * (more, lighter blocks; same bits).
  * Host pipeline of b2f_compute_flow*: host_subbatch_pixels, host_threads (0 = auto), host_u8,
  * host_ramp.  The library reads no environment variable after b2f_init (which takes
  * B2F_<OPTION> as the initial value of the tuning options).                              */

@@ -1146,3 +1146,25 @@ def test_stride2_loader_consumer_kernel(hard, B, ci, co, h, w, scale, blocks):
     assert np.array_equal(got, got1)
     if (co & 3) == 0:
         assert np.array_equal(got, bf6)
+
+
+@pytest.mark.parametrize("B,ci,co,h,w", [(1, 64, 32, 16, 30), (1, 200, 128, 16, 30), (1, 128, 96, 32, 60), (3, 96, 64, 9, 17), (1, 40, 32, 8, 16), (2, 72, 160, 17, 33),
+                                         (1, 562, 128, 16, 30), (1, 8, 32, 1, 1), (1, 136, 64, 64, 120)])
+def test_conv3x3_wino_eight_wave_form_bit_identical(hard, B, ci, co, h, w):
+    """conv3x3_wino8 (option wino8, default on): the one-N-tile F(2x2) launches of at most one block per CU -- a single triplet's coarse
+    levels -- on 512-thread blocks whose waves multiply one xi pair each.  Same operations per output in the same order: the bits of the
+    four-wave kernel, split into 32-output blocks or not, and the oracle's values at the F(2x2) bar."""
+    r = _rng(ci + 3 * co + h)
+    x = r.standard_normal((B, ci, h, w), dtype=np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = r.standard_normal(co, dtype=np.float32)
+    big = 1 << 30
+    with hard.options(wino8=0, wino4_min_pixels=big, wino_split_pixels=big):
+        a4 = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino8=1, wino4_min_pixels=big, wino_split_pixels=big):
+        a8 = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino8=1, wino4_min_pixels=big, wino_split_pixels=0):
+        a8n = ops.conv3x3(hard, x, wt, b, 1, True)
+    np.testing.assert_array_equal(a4, a8)
+    np.testing.assert_array_equal(a4, a8n)
+    np.testing.assert_allclose(a8, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=2e-5)

@@ -8,7 +8,8 @@ import torch
 import bench
 from back2future_amd import back2future
 
-B, H, W = 16, 1024, 1920
+import os
+B, H, W = int(os.environ.get("CORR_AB_BATCH", "16")), 1024, 1920
 m = back2future.Model("random:hard:2:1.0")
 dev = torch.device("cuda", 0)
 x = bench.make_triplets(torch, B, H, W, seed=2, device=dev)
