@@ -774,7 +774,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     f32x4 sr[3];
     // next item of the load stream -> sr; after a tile's last chunk the stream moves on to the block's next tile (and
     // keeps re-reading the very last chunk when there is none: harmless).  Scalar work only at the switch.
-#define W4P_LOAD_STREAM()                                                                           \
+#define W4P_LOAD_STREAM() W4P_LOAD_STREAM_TO(sr)
+#define W4P_LOAD_STREAM_TO(sr_)                                                                     \
     do {                                                                                            \
         const bool s1 = lc >= p.seg[0].nchunks;                                                     \
         const long cstr = s1 ? p.seg[1].chunk_stride : p.seg[0].chunk_stride;                       \
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
             unsigned vo__;                                                                          \
             asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(vo__) : "v"(l_off), "s"(mk[i]));         \
-            sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)vo__, so + i * rowblk, 0)); \
+            sr_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s1 ? r_rsrc1 : r_rsrc0, (int)vo__, so + i * rowblk, 0)); \
         }                                                                                           \
         if (++lc == nchunks) {                                                                      \
             if (has_next) {                                                                         \
@@ -795,10 +796,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             }                                                                                       \
         }                                                                                           \
     } while (0)
-#define W4P_WRITE_RAW(buf_)                                                                         \
+#define W4P_WRITE_RAW(buf_) W4P_WRITE_RAW_FROM(buf_, sr)
+#define W4P_WRITE_RAW_FROM(buf_, sr_)                                                               \
     do {                                                                                            \
         f32x4 *r = Rb + (buf_) * RAW_F4;                                                            \
-        if (s_act) { W4_RAW_STORE(r, s_slot, sr[0]); W4_RAW_STORE(r, s_slot + 6 * RWP, sr[1]); W4_RAW_STORE(r, s_slot + 12 * RWP, sr[2]); } \
+        if (s_act) { W4_RAW_STORE(r, s_slot, sr_[0]); W4_RAW_STORE(r, s_slot + 6 * RWP, sr_[1]); W4_RAW_STORE(r, s_slot + 12 * RWP, sr_[2]); } \
     } while (0)
 
     // ---- input transform role (as in conv3x3_wino4: row pairs with shared sub-expressions, channel pair th = wave & 1) ----
@@ -1219,6 +1221,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         }
         W4P_WRITE_RAW(1);
     }
+    // The raw patch THREE chunks ahead where the chunk count allows static register roles (even, >= 4: every layer of the shipped
+    // graph that runs this form): two register sets, a set is loaded at the top of a chunk and written to LDS at the end of the NEXT one
+    // -- two chunk periods of cover; with one set (load and write in the same chunk) the write waited out most of an HBM round trip.
+    const bool two_sets = (nchunks & 1) == 0 && nchunks >= 4;
+    f32x4 sq[3];
+    if (two_sets) W4P_LOAD_STREAM();             // chunk 2, stays in flight
     __syncthreads();
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) { W4_T_READ(s2, 0); W4_T_FMA(s2, 0); }
@@ -1233,31 +1241,39 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         for (int x = 0; x < 5; ++x)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            const int pc = (par + c) & 1;
-            const int cn = c + 1 < nchunks ? c + 1 : 0;          // after the last chunk: chunk 0 of the next tile (same weights)
-            W4Q_LOAD_U(bn, cn);
-            W4P_LOAD_STREAM();                                   // two chunks ahead (runs on into the next tile)
-            const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_lane;
-#pragma unroll
-            for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);
-#pragma unroll
-            for (int x = 0; x < 5; ++x) {
-                if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 2); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x < 4 || n == 0)       // the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch)
-                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (x < 4) { W4_T_FMA_D(2 * x, 0, pc ^ 1); W4_T_FMA_D(2 * x + 1, 2, pc ^ 1); }
-                else { W4P_WRITE_RAW(pc); }
-                __builtin_amdgcn_sched_barrier(0);
+        // one chunk: LD_ = the stream load issued at its top, WR_ = the register set written to LDS at its end
+#define W4Q_CHUNK(c_, LD_, WR_)                                                                     \
+        do {                                                                                        \
+            const int c = (c_);                                                                     \
+            const int pc = (par + c) & 1;                                                           \
+            const int cn = c + 1 < nchunks ? c + 1 : 0;          /* after the last chunk: chunk 0 of the next tile (same weights) */ \
+            W4Q_LOAD_U(bn, cn);                                                                     \
+            LD_;                                                 /* runs on into the next tile */   \
+            const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_lane;          \
+            _Pragma("unroll") for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);      \
+            _Pragma("unroll") for (int x = 0; x < 5; ++x) {                                         \
+                if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 2); }    \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+                    if (x < 4 || n == 0)       /* the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch) */ \
+                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                if (x < 4) { W4_T_FMA_D(2 * x, 0, pc ^ 1); W4_T_FMA_D(2 * x + 1, 2, pc ^ 1); }      \
+                else { W4P_WRITE_RAW_FROM(pc, WR_); }                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            }                                                                                       \
+            __syncthreads();                                                                        \
+            _Pragma("unroll") for (int x = 0; x < 5; ++x) bc[x] = bn[x];                            \
+        } while (0)
+        if (two_sets) {
+            for (int c2 = 0; c2 < nchunks; c2 += 2) {
+                W4Q_CHUNK(c2, W4P_LOAD_STREAM_TO(sq), sr);       // chunk c + 3 -> sq; sr (chunk c + 2, loaded a chunk ago) -> LDS
+                W4Q_CHUNK(c2 + 1, W4P_LOAD_STREAM_TO(sr), sq);
             }
-            __syncthreads();
-#pragma unroll
-            for (int x = 0; x < 5; ++x) bc[x] = bn[x];
+        } else {
+            for (int c1 = 0; c1 < nchunks; ++c1) W4Q_CHUNK(c1, W4P_LOAD_STREAM_TO(sr), sr);   // two chunks ahead, one register set
         }
+#undef W4Q_CHUNK
         // ---- output: two passes (tile rows 2h, 2h + 1) through the dead V buffer + gap ----
         const int pl = (par + nchunks - 1) & 1;
         float *X = reinterpret_cast<float *>(Vb + pl * V_F4);
@@ -1349,7 +1365,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #undef W4P_RSRC_U
 #undef W4P_HYB
 #undef W4P_WRITE_RAW
+#undef W4P_WRITE_RAW_FROM
 #undef W4P_LOAD_STREAM
+#undef W4P_LOAD_STREAM_TO
 #undef W4P_RSRC
 #undef W4P_MASKS
 #undef W4P_DECODE

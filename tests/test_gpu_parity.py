@@ -1167,4 +1167,4 @@ def test_conv3x3_wino_eight_wave_form_bit_identical(hard, B, ci, co, h, w):
         a8n = ops.conv3x3(hard, x, wt, b, 1, True)
     np.testing.assert_array_equal(a4, a8)
     np.testing.assert_array_equal(a4, a8n)
-    np.testing.assert_allclose(a8, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a8, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=1e-4)      # F(2x2) rounding on up to 562 input channels
