@@ -821,6 +821,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     int t_dst = ((t_orow * 6 * 2 + t_k4) * 2 + th) * 32 + t_tile;
     f32x4 R[6], d[NTV == 1 ? 4 : 2];
 
+#if B2F_WINO_TRACE
+    const int trp_slot = blockIdx.x == 40 ? 0 : blockIdx.x == 41 ? 1 : -1;
+    const bool trp_on = p.trace && trp_slot >= 0 && (wave == 0 || wave == 4) && lane == 0;
+    long long *trp_buf = p.trace + (trp_on ? (trp_slot * 2 + (wave >> 2)) * 160 : 0);
+    int trp_tile = 0;
+#define W4P_T(k_) do { if (trp_on && trp_tile < 12) trp_buf[trp_tile * 12 + (k_)] = clock64(); } while (0)
+    // step-level stamps of tile 3, chunks 8..11 (4 per xi step: step start | before the multiplications | after them | after the
+    // transform slice), kept in the spare LDS behind the kernel's buffers and copied out after the tile
+    long long *ts_lds = reinterpret_cast<long long *>(smem + P_LDS_BYTES) + (wave >> 2) * 144;
+#define W4P_TS(c_, x_, k_) do { if (trp_on && trp_tile == 3 && (c_) >= 8 && (c_) < 12) ts_lds[(((c_) - 8) * 9 + (x_)) * 4 + (k_)] = clock64(); } while (0)
+#else
+#define W4P_T(k_) do {} while (0)
+#define W4P_TS(c_, x_, k_) do {} while (0)
+#endif
     if constexpr (NTV == 2) {
     f32x16 acc[9];
     int a_off = (9 * g * 2 + half) * 2 * 32 + m;
@@ -867,20 +881,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         }                                                                                           \
     } while (0)
 
-#if B2F_WINO_TRACE
-    const int trp_slot = blockIdx.x == 40 ? 0 : blockIdx.x == 41 ? 1 : -1;
-    const bool trp_on = p.trace && trp_slot >= 0 && (wave == 0 || wave == 4) && lane == 0;
-    long long *trp_buf = p.trace + (trp_on ? (trp_slot * 2 + (wave >> 2)) * 160 : 0);
-    int trp_tile = 0;
-#define W4P_T(k_) do { if (trp_on && trp_tile < 12) trp_buf[trp_tile * 12 + (k_)] = clock64(); } while (0)
-    // step-level stamps of tile 3, chunks 8..11 (4 per xi step: step start | before the multiplications | after them | after the
-    // transform slice), kept in the spare LDS behind the kernel's buffers and copied out after the tile
-    long long *ts_lds = reinterpret_cast<long long *>(smem + P_LDS_BYTES) + (wave >> 2) * 144;
-#define W4P_TS(c_, x_, k_) do { if (trp_on && trp_tile == 3 && (c_) >= 8 && (c_) < 12) ts_lds[(((c_) - 8) * 9 + (x_)) * 4 + (k_)] = clock64(); } while (0)
-#else
-#define W4P_T(k_) do {} while (0)
-#define W4P_TS(c_, x_, k_) do {} while (0)
-#endif
     // ---- first tile: prologue as in the one-tile kernel ----
     if ((int)blockIdx.x >= total) return;
     W4P_DECODE((int)blockIdx.x, cur_nb, cur_img, cur_ox0, cur_oy0);
@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             W4P_DECODE(v_cur + G, nxt_nb, nxt_img, nxt_ox0, nxt_oy0);
             W4P_MASKS(nxt_ox0, nxt_oy0, mk_n);
         }
+        W4P_T(0);
 #pragma unroll
         for (int x = 0; x < 5; ++x)
 #pragma unroll
@@ -1247,23 +1248,31 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             const int c = (c_);                                                                     \
             const int pc = (par + c) & 1;                                                           \
             const int cn = c + 1 < nchunks ? c + 1 : 0;          /* after the last chunk: chunk 0 of the next tile (same weights) */ \
+            W4P_TS(c, 5, 3);                                                                        \
             W4Q_LOAD_U(bn, cn);                                                                     \
             LD_;                                                 /* runs on into the next tile */   \
             const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_lane;          \
             _Pragma("unroll") for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);      \
             _Pragma("unroll") for (int x = 0; x < 5; ++x) {                                         \
+                W4P_TS(c, x, 0);                                                                    \
                 if (x < 4) { W4_T_READ_D(2 * x, pc ^ 1, 0); W4_T_READ_D(2 * x + 1, pc ^ 1, 2); }    \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 1);                                                                    \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
                     if (x < 4 || n == 0)       /* the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch) */ \
                         acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 2);                                                                    \
                 if (x < 4) { W4_T_FMA_D(2 * x, 0, pc ^ 1); W4_T_FMA_D(2 * x + 1, 2, pc ^ 1); }      \
                 else { W4P_WRITE_RAW_FROM(pc, WR_); }                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
+                W4P_TS(c, x, 3);                                                                    \
             }                                                                                       \
+            W4P_TS(c, 5, 0);                                                                        \
             __syncthreads();                                                                        \
+            W4P_TS(c, 5, 1);                                                                        \
             _Pragma("unroll") for (int x = 0; x < 5; ++x) bc[x] = bn[x];                            \
+            W4P_TS(c, 5, 2);                                                                        \
         } while (0)
         if (two_sets) {
             for (int c2 = 0; c2 < nchunks; c2 += 2) {
@@ -1274,6 +1283,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             for (int c1 = 0; c1 < nchunks; ++c1) W4Q_CHUNK(c1, W4P_LOAD_STREAM_TO(sr), sr);   // two chunks ahead, one register set
         }
 #undef W4Q_CHUNK
+        W4P_T(1);
         // ---- output: two passes (tile rows 2h, 2h + 1) through the dead V buffer + gap ----
         const int pl = (par + nchunks - 1) & 1;
         float *X = reinterpret_cast<float *>(Vb + pl * V_F4);
@@ -1350,10 +1360,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
         W4Q_LDS_BARRIER();                                                                          \
     } while (0)
         W4Q_PASS(0);
+        W4P_T(2);
         W4Q_PASS(1);
+        W4P_T(3);
 #undef W4Q_PASS
 #undef W4Q_LDS_BARRIER
         par = pl ^ 1;
+#if B2F_WINO_TRACE
+        if (trp_on && trp_tile == 0) trp_buf[157] = wall_clock64();
+        if (trp_on && trp_tile == 11) { trp_buf[158] = wall_clock64(); trp_buf[159] = clock64(); }
+        if (trp_on && trp_tile == 3)
+            for (int i = 0; i < 144; ++i) p.trace[1280 + (trp_slot * 2 + (wave >> 2)) * 144 + i] = ts_lds[i];
+        ++trp_tile;
+#endif
         if (!has_next) break;
         v_cur += G;
         cur_nb = nxt_nb; cur_img = nxt_img; cur_ox0 = nxt_ox0; cur_oy0 = nxt_oy0;
@@ -1417,7 +1436,7 @@ static hipError_t launch_wino4_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     static int traced = 0;
     // B2F_WINO_TRACE=<total chunks of the layer to trace> (1 = the 16-chunk single-segment layer)
     const int tr_want = getenv("B2F_WINO_TRACE") ? atoi(getenv("B2F_WINO_TRACE")) : 0;
-    const bool do_trace = tr_want > 0 && traced < 1 && NTV == 2 && p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0) == (tr_want == 1 ? 16 : tr_want) && p.H * p.W >= 256 * 480;
+    const bool do_trace = tr_want > 0 && traced < 1 && NTV == (getenv("B2F_WINO_TRACE_NTV1") ? 1 : 2) && p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0) == (tr_want == 1 ? 16 : tr_want) && p.H * p.W >= 256 * 480;
     if (do_trace) {
         if (!trace_dev) hipMalloc(&trace_dev, 32 * 160 * sizeof(long long));     // [0, 640) tile stamps, [1280, 1856) step stamps
         hipMemsetAsync(trace_dev, 0, 32 * 160 * sizeof(long long), s);
