@@ -22,7 +22,8 @@ def main():
     maxn = int(sys.argv[5]) if len(sys.argv) > 5 else 6
     models = {"hard": back2future.Model("random:hard:3:2.0"), "soft": back2future.Model("random:soft:3:2.0")}
     for m in models.values():
-        m.set_option("wino4_min_pixels", 4096)       # kernel choice independent of the batch: bit-identical results (the default)
+        m.set_option("wino4_min_pixels", 4096)
+        m.set_option("adaptive_kernels", 0)          # kernel choice independent of the batch: bit-identical results (the default -1 picks per launch for single-triplet calls)
     free0 = None
     t0 = time.time()
     for it in range(iters):
