@@ -849,7 +849,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc, (int)b_off, (int)((c_) * USC_BYTES + (x_) * 2048), 0)); \
             bl[slot_] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ws_rsrc, (int)(b_off >> 1), (int)((c_) * USC_BYTES + US4_BYTES + (x_) * 1024), 0)); \
         } else {                                                                                    \
-            bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((c_) * (U_F4 * 16) + (x_) * 2048), 0)); \
+            bv[slot_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_off, (int)((B2F_W4_BHOT ? 0 : (c_)) * (U_F4 * 16) + (B2F_W4_BHOT == 2 ? 0 : (x_)) * 2048), 0)); \
         }                                                                                           \
     } while (0)
 #define W4P_RSRC_U(nb_)                                                                             \
@@ -861,6 +861,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
     } while (0)
     // the multiplications of xi step x_: four fp32 MFMAs, or (hybrid step) the split of the A operand and three bf16 MFMAs
     // through one accumulator, strictly back to back
+#ifndef B2F_W4_BHOT
+#define B2F_W4_BHOT 0      // TIMING EXPERIMENT (wrong results): 1 = every chunk reads chunk 0's weights (L2-resident), 2 = every step the same 2 KB (L1-resident); data stays random
+#endif
+#ifndef B2F_W4_MFMA16_TIMING
+#define B2F_W4_MFMA16_TIMING 0
+#endif
+    // one K pair of xi step x_: a v_mfma_f32_32x32x2_f32 -- or, TIMING EXPERIMENT (wrong results), the same MACs as two
+    // v_mfma_f32_16x16x4_f32 on two quarters of the accumulator (tools/mfma_f32_power.hip: that instruction sustains 155 TFLOP/s at 2.39 GHz
+    // where the 32x32x2 form is clocked down to 2.17 - 2.27 GHz: half the accumulator traffic per MAC)
+#if B2F_W4_MFMA16_TIMING
+#define W4P_MF(x_, j_, b_)                                                                          \
+    do {                                                                                            \
+        f32x4 q0__ = __builtin_shufflevector(acc[x_], acc[x_], 4 * ((j_) & 1), 4 * ((j_) & 1) + 1, 4 * ((j_) & 1) + 2, 4 * ((j_) & 1) + 3); \
+        f32x4 q1__ = __builtin_shufflevector(acc[x_], acc[x_], 8 + 4 * ((j_) & 1), 9 + 4 * ((j_) & 1), 10 + 4 * ((j_) & 1), 11 + 4 * ((j_) & 1)); \
+        q0__ = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(x_) % 3][j_], (b_)[j_], q0__, 0, 0, 0);     \
+        q1__ = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(x_) % 3][j_], (b_)[((j_) + 1) & 3], q1__, 0, 0, 0); \
+        _Pragma("unroll") for (int r__ = 0; r__ < 4; ++r__) { acc[x_][4 * ((j_) & 1) + r__] = q0__[r__]; acc[x_][8 + 4 * ((j_) & 1) + r__] = q1__[r__]; } \
+    } while (0)
+#else
+#define W4P_MF(x_, j_, b_) acc[x_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(x_) % 3][j_], (b_)[j_], acc[x_], 0, 0, 0)
+#endif
 #define W4P_MULT(x_, slot_)                                                                         \
     do {                                                                                            \
         if (W4P_HYB(x_)) {                                                                          \
@@ -876,8 +897,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hl), __builtin_bit_cast(bf16x8, bq__), acc[x_], 0, 0, 0); \
             acc[x_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_mh), __builtin_bit_cast(bf16x8, b_hl), acc[x_], 0, 0, 0); \
         } else {                                                                                    \
+            if (B2F_W4_MFMA16_TIMING) {   /* TIMING EXPERIMENT (wrong results): the same MACs as eight v_mfma_f32_16x16x4_f32 */ \
+                f32x4 q__[4];                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) q__[j] = f32x4{acc[x_][4 * j], acc[x_][4 * j + 1], acc[x_][4 * j + 2], acc[x_][4 * j + 3]}; \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+                    q__[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(x_) % 3][j], bv[slot_][j], q__[j], 0, 0, 0); \
+                    q__[(j + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[(x_) % 3][j], bv[slot_][(j + 1) & 3], q__[(j + 2) & 3], 0, 0, 0); \
+                }                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[x_][4 * j + r] = q__[j][r];   \
+            } else {                                                                                \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
                 acc[x_] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(x_) % 3][j], bv[slot_][j], acc[x_], 0, 0, 0); \
+            }                                                                                       \
         }                                                                                           \
     } while (0)
 
@@ -990,22 +1022,22 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
                 else if (x == 8) W4_T_FMA(1, 0);                                                    \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 W4P_TS(c, x, 1);                                                                    \
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][0], bv[(9 * (PH_) + x) % 6][0], acc[x], 0, 0, 0); \
+                W4P_MF(x, 0, bv[(9 * (PH_) + x) % 6]);                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 /* rows of the next slice first: they are needed soonest (at the start of the next step) */ \
                 if (x < 6) { if (x + 3 < 8) W4_T_READ(x + 3, pc ^ 1); }                             \
                 else if (x == 7) W4_T_READ(1, pc);                                                  \
                 else if (x == 8) W4_T_READ(2, pc);                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][1], bv[(9 * (PH_) + x) % 6][1], acc[x], 0, 0, 0); \
+                W4P_MF(x, 1, bv[(9 * (PH_) + x) % 6]);                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 W4P_STEP_LOAD_U(PH_, x, LAST_);                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][2], bv[(9 * (PH_) + x) % 6][2], acc[x], 0, 0, 0); \
+                W4P_MF(x, 2, bv[(9 * (PH_) + x) % 6]);                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 W4P_STEP_A_READS(x);                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x % 3][3], bv[(9 * (PH_) + x) % 6][3], acc[x], 0, 0, 0); \
+                W4P_MF(x, 3, bv[(9 * (PH_) + x) % 6]);                                              \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 W4P_TS(c, x, 2);                                                                    \
                 if (x == 6) {                                                                       \
