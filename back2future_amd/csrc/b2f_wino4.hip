@@ -1275,14 +1275,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
         // one chunk: LD_ = the stream load issued at its top, WR_ = the register set written to LDS at its end
-#define W4Q_CHUNK(c_, LD_, WR_)                                                                     \
+#define W4Q_CHUNK(c_, LD_, WR_, BC_, BN_, COPY_)                                                     \
         do {                                                                                        \
             const int c = (c_);                                                                     \
             const int pc = (par + c) & 1;                                                           \
             const int cn = c + 1 < nchunks ? c + 1 : 0;          /* after the last chunk: chunk 0 of the next tile (same weights) */ \
             W4P_TS(c, 5, 3);                                                                        \
-            W4Q_LOAD_U(bn, cn);                                                                     \
-            LD_;                                                 /* runs on into the next tile */   \
             const f32x2 *Vc = reinterpret_cast<const f32x2 *>(Vb + pc * VSTRIDE) + a_lane;          \
             _Pragma("unroll") for (int x = 0; x < 5; ++x) av[x] = W4_A_READ(Vc + xo[x] * 128);      \
             _Pragma("unroll") for (int x = 0; x < 5; ++x) {                                         \
@@ -1292,9 +1290,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
                 W4P_TS(c, x, 1);                                                                    \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
                     if (x < 4 || n == 0)       /* the fifth step of the n = 1 waves would be a duplicate (only MFMAs sit behind this branch) */ \
-                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], bc[x][j], acc[x], 0, 0, 0); \
+                        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][j], BC_[x][j], acc[x], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
                 W4P_TS(c, x, 2);                                                                    \
+                /* this step's share of the vector-memory issue: the B operand of xi step x of the next chunk, the raw-patch stream at x = 1 \
+                   (bunched at the chunk's top both waves of a SIMD queued ~500 cycles of load issue right behind the barrier) */ \
+                BN_[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_lane, (int)(cn * (U_F4 * 16) + xo[x] * 2048), 0)); \
+                if (x == 1) { LD_; }                             /* runs on into the next tile */   \
                 if (x < 4) { W4_T_FMA_D(2 * x, 0, pc ^ 1); W4_T_FMA_D(2 * x + 1, 2, pc ^ 1); }      \
                 else { W4P_WRITE_RAW_FROM(pc, WR_); }                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -1303,16 +1305,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4p(const ConvLaunch p)
             W4P_TS(c, 5, 0);                                                                        \
             __syncthreads();                                                                        \
             W4P_TS(c, 5, 1);                                                                        \
-            _Pragma("unroll") for (int x = 0; x < 5; ++x) bc[x] = bn[x];                            \
+            if (COPY_) { _Pragma("unroll") for (int x = 0; x < 5; ++x) bc[x] = bn[x]; }             \
             W4P_TS(c, 5, 2);                                                                        \
         } while (0)
-        if (two_sets) {
+        if (two_sets) {   // static roles: the B registers alternate too (no copy)
             for (int c2 = 0; c2 < nchunks; c2 += 2) {
-                W4Q_CHUNK(c2, W4P_LOAD_STREAM_TO(sq), sr);       // chunk c + 3 -> sq; sr (chunk c + 2, loaded a chunk ago) -> LDS
-                W4Q_CHUNK(c2 + 1, W4P_LOAD_STREAM_TO(sr), sq);
+                W4Q_CHUNK(c2, W4P_LOAD_STREAM_TO(sq), sr, bc, bn, false);    // chunk c + 3 -> sq; sr (chunk c + 2, loaded a chunk ago) -> LDS
+                W4Q_CHUNK(c2 + 1, W4P_LOAD_STREAM_TO(sr), sq, bn, bc, false);
             }
         } else {
-            for (int c1 = 0; c1 < nchunks; ++c1) W4Q_CHUNK(c1, W4P_LOAD_STREAM_TO(sr), sr);   // two chunks ahead, one register set
+            for (int c1 = 0; c1 < nchunks; ++c1) W4Q_CHUNK(c1, W4P_LOAD_STREAM_TO(sr), sr, bc, bn, true);   // two chunks ahead, one register set
         }
 #undef W4Q_CHUNK
         W4P_T(1);
