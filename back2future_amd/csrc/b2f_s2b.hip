@@ -369,7 +369,7 @@ hipError_t launch_conv3x3_s2b(const ConvLaunch &p, hipStream_t s)
     // a launch whose blocks cannot fill the chip (single triplets, the coarse levels): one output tile per block, the four consumers
     // take one pixel tile each -- NT x the blocks, a quarter of the MFMAs in a row per wave (p.nsplit < 0 switches it off: option s2_tile_groups = 0)
     if (p.nsplit >= 0 && total * ((NT + 3) / 4) * 2 <= cap && total * NT <= 2 * cap) {
-        const int gp = total * NT <= cap ? total : cap / NT;
+        const int gp = total * NT <= cap ? total : (cap / NT > 0 ? cap / NT : 1);
         q.nb0 = 0;
         q.nsplit = NT;
         return s2b_launch_t<1, 1>(q, gp * NT, s);

@@ -1116,7 +1116,7 @@ def test_direct_kernels_everywhere_end_to_end():
 
 @pytest.mark.parametrize("B,ci,co,h,w,scale,blocks", [(1, 64, 96, 16, 64, 1.0, 1), (2, 32, 64, 37, 71, 1.0, 3), (1, 64, 96, 33, 50, 300.0, 1), (3, 96, 128, 9, 130, 1e-3, 2),
                                                       (1, 128, 192, 32, 60, 1.0, 1), (2, 40, 64, 20, 20, 1.0, 1), (1, 64, 100, 31, 33, 1.0, 7), (1, 24, 32, 40, 66, 1.0, 1),
-                                                      (1, 8, 256, 2, 2, 1.0, 1), (4, 16, 36, 1, 1, 1.0, 1), (3, 72, 160, 64, 48, 1.0, 5)])
+                                                      (1, 8, 256, 2, 2, 1.0, 1), (4, 16, 36, 1, 1, 1.0, 1), (3, 72, 160, 64, 48, 1.0, 5), (1, 64, 96, 8, 16, 1.0, 2)])
 def test_stride2_loader_consumer_kernel(hard, B, ci, co, h, w, scale, blocks):
     """b2f_s2b.hip (option s2_loader; 2 = every stride-2 layer, the default 1 = those of at least 64 input channels): the stride-2 convs of
     pwc.lua:60 on the bf16 pipe with split fp32 operands in loader / consumer persistent blocks that compute all outputs of a tile.
