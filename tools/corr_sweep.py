@@ -18,8 +18,8 @@ for it in range(n):
         h, w = int(rng.integers(60, 140)), int(rng.integers(100, 300))     # several tiles per block of the persistent kernel
     B = int(rng.integers(1, 4))
     k = float(rng.choice([0.3125, 0.625, 1.25, 2.5, 5.0]))
-    var = int(rng.integers(4))
-    m.set_option("corr_variant", var)      # 0 regular, 1 latency, 2 two-pixel instantiation
+    var = int(rng.choice([-1, 0, 1, 3, 5, 7]))   # the product library's instantiations (-1: the launcher's choice)
+    m.set_option("corr_variant", var)
     ref = rng.standard_normal((B, C, h, w), dtype=np.float32)
     f3 = rng.standard_normal((B, C, h, w), dtype=np.float32)
     f1 = rng.standard_normal((B, C, h, w), dtype=np.float32)
