@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libb2f.so")
 BUILD = os.path.join(HERE, "build")
-SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_w1b.hip", "b2f_s2b.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
+SOURCES = ["b2f_conv.hip", "b2f_wino.hip", "b2f_wino4.hip", "b2f_wino6.hip", "b2f_w1b.hip", "b2f_s2b.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_corr.hip", "b2f_corr5.hip", "b2f_glue.hip", "b2f_boundary.hip", "b2f_api.hip", "b2f_graph.hip", "b2f_backward.hip", "b2f_pipeline.hip", "b2f_multi.hip", "b2f_host.cpp", "b2f_t7.cpp"]
 HEADERS = ["b2f_internal.h", "b2f_host.h", "b2f_ctx.h", "b2f_corr5_loop.inc", os.path.join("..", "..", "include", "b2f.h")]
 # tools/experiments/csrc: kernels that were built, tested and measured no faster than the defaults; `--experiments` builds them and
 # the options that select them into libb2f_exp.so (B2F_LIB=<that file>); the product library does not contain them
@@ -27,6 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # operands are not register-adjacent, which costs ~2 v_mov per FMA; plain v_fmac is faster here.
 # b2f_wino4s: packed fp32 ops do not overlap the bf16 MFMAs (tools/mfma_bf16_chain.hip); its VALU work is written scalar on purpose.
 EXTRA = {"b2f_corr.hip": ["-fno-slp-vectorize"], "b2f_corr5.hip": ["-fno-slp-vectorize"], "b2f_wino4s.hip": ["-fno-slp-vectorize"], "b2f_wino2s.hip": ["-fno-slp-vectorize"], "b2f_conv16b.hip": ["-fno-slp-vectorize"], "b2f_head.hip": ["-fno-slp-vectorize"], "b2f_convb.hip": ["-fno-slp-vectorize"], "b2f_w1b.hip": ["-fno-slp-vectorize"], "b2f_s2b.hip": ["-fno-slp-vectorize"]}
+
 
 
 def _stale(target, deps):

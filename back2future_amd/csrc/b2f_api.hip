@@ -193,6 +193,13 @@ int pack_all(b2f_ctx *c, const float *flat)
             p.b_off7 = total;
             total += (size_t)s2b_ntiles(d.co) * 32;
         }
+        if (p.wino == 4 && c->wino6 && d.co >= 64 - 31) {   // only while the option reads it; layers whose one block has <= 32 outputs never use it
+            total = (total + 3) & ~(size_t)3;
+            p.w_off8 = total;
+            total += wino6_wpk_floats(chunks, d.co);
+            p.b_off8 = total;
+            total += (size_t)wino6_nblk(d.co) * 64;
+        }
         if (p.wino == 4 && c->wino1d) {   // only while the option reads it (as the other optional packings)
             total = (total + 3) & ~(size_t)3;
             p.w_off6 = total;
@@ -246,6 +253,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             if (p.w_off3) wino4s_pack_weights(flat + d.w_off, d.co, d.ci, maps[i].data(), chunks, p.nblk, host.data() + p.w_off3);
 #endif
             if (p.w_off6) w1b_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off6, host.data() + p.b_off6);
+            if (p.w_off8) wino6_pack_weights(flat + d.w_off, flat + d.b_off, d.co, d.ci, maps[i].data(), chunks, host.data() + p.w_off8, host.data() + p.b_off8);
         } else if (p.wino == 1)
             narrow2_pack_weights(flat + d.w_off, flat + d.b_off, d.ci, maps[i].data(), chunks, host.data() + p.w_off,
                                  host.data() + p.b_off);
@@ -445,13 +453,20 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
         L.w1b_nblk = w1d_blocks;
         w1d = w1b_supported(L);
     }
+    // wino6 = 1: the n-blocks with more than 32 real outputs on the F(6x6) kernel, a last block of <= 32 outputs on the F(4x4) single-N-tile kernel
+    const int w6_blocks = p.cout / 64 + (p.cout % 64 > 32 ? 1 : 0);
+    bool w6 = !bf6 && !w1d && mode == 4 && stride == 1 && c->wino6 && p.w_off8 && w6_blocks > 0 && H * W >= c->wino6_min_pixels;
+    if (w6) {
+        L.wpk_w6 = c->wpk_dev + p.w_off8; L.bias_w6 = c->wpk_dev + p.b_off8;
+        w6 = wino6_supported(L);
+    }
     char name[48];
     const bool per_layer = c->profile_layers != 0;   // one profile row per (layer shape, map size)
     if (per_layer)
-        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", s2l ? "L2" : bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : mode == 4 ? "W4" : mode == 3 ? ((B2F_EXPERIMENTS && c->bf16_direct) ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
+        snprintf(name, sizeof name, "conv%s_%dto%d_%dx%d", s2l ? "L2" : bf6 ? (stride == 1 ? "E1" : "E2") : w1d ? "V1" : w6 ? "W6" : mode == 4 ? "W4" : mode == 3 ? ((B2F_EXPERIMENTS && c->bf16_direct) ? "B16" : "C16") : mode == 5 ? "S16" : mode == 2 ? "W2" : mode == 1 ? "N2" : stride == 1 ? "D1" : "D2",
                  (p.chunks[0] + (p.nseg > 1 ? p.chunks[1] : 0)) * 8, p.cout, H, W);
     else
-        snprintf(name, sizeof name, s2l ? "conv3x3_s2b_%d" : bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
+        snprintf(name, sizeof name, s2l ? "conv3x3_s2b_%d" : bf6 ? (stride == 1 ? "conv3x3_s1_bf16_%d" : "conv3x3_s2_bf16_%d") : w1d ? "conv3x3_w1b_%d" : w6 ? "conv3x3_wino6_nt%d" : mode == 4 ? "conv3x3_wino4_nt%d" : mode == 3 ? "conv3x3_c16_%d" : mode == 5 ? "conv3x3_s2x16_%d" : mode == 2 ? "conv3x3_wino_nt%d"
                                     : mode == 1 ? "conv3x3_narrow%d" : (stride == 1 ? "conv3x3_s1_nt%d" : "conv3x3_s2_nt%d"),
                  mode == 1 ? 2 : nt);
     Scope sc(c, s, name, cap);
@@ -460,6 +475,10 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
     else if (w1d) {
         HIPCHK(launch_conv3x3_w1b(L, s));
         if (w1d_blocks < w1b_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
+    }
+    else if (w6) {
+        HIPCHK(launch_conv3x3_wino6(L, 0, w6_blocks, s));
+        if (w6_blocks < wino6_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
     }
     else if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
@@ -848,6 +867,8 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->profile_layers = (int)env_int("B2F_PROFILE_LAYERS", c->profile_layers);
         c->wino4_persistent = (int)env_int("B2F_WINO4_PERSISTENT", c->wino4_persistent);
         c->wino1d = (int)env_int("B2F_WINO1D", c->wino1d);
+        c->wino6 = (int)env_int("B2F_WINO6", c->wino6);
+        c->wino6_min_pixels = (int)env_int("B2F_WINO6_MIN_PIXELS", c->wino6_min_pixels);
         c->s2_loader = (int)env_int("B2F_S2_LOADER", c->s2_loader);
         c->s2_tile_groups = (int)env_int("B2F_S2_TILE_GROUPS", c->s2_tile_groups);
 #if B2F_EXPERIMENTS
@@ -990,6 +1011,17 @@ int b2f_set_option(b2f_ctx *c, const char *key, int value) try
         c->wino1d = value;
         if (had != (value != 0)) CHK(b2f_commit_weights(c));   // the packing exists only while the option reads it
     }
+    else if (!strcmp(key, "wino6") || !strcmp(key, "wino6_min_pixels")) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        drop_graphs(c);
+        if (key[5] == '_') c->wino6_min_pixels = value;
+        else {
+            const bool had = c->wino6 != 0;
+            c->wino6 = value;
+            if (had != (value != 0)) CHK(b2f_commit_weights(c));   // the packing exists only while the option reads it
+        }
+    }
 #if !B2F_EXPERIMENTS
     else if (!strcmp(key, "wino2_split") || !strcmp(key, "wino4_split") || !strcmp(key, "wino4_hybrid")) {
         if (value != 0) return fail(std::string("b2f_set_option: ") + key + " selects an experiment kernel (tools/experiments/csrc): build with `python -m back2future_amd.build --experiments` and load libb2f_exp.so");
@@ -1066,6 +1098,8 @@ int b2f_get_option(const b2f_ctx *c, const char *key, int *value) try
     else if (k == "wino4_persistent") *value = c->wino4_persistent;
     else if (k == "experiments") *value = B2F_EXPERIMENTS;
     else if (k == "wino1d") *value = c->wino1d;
+    else if (k == "wino6") *value = c->wino6;
+    else if (k == "wino6_min_pixels") *value = c->wino6_min_pixels;
     else if (k == "s2_loader") *value = c->s2_loader;
     else if (k == "s2_tile_groups") *value = c->s2_tile_groups;
     else if (k == "wino4_split") *value = c->wino4_split;
@@ -1514,6 +1548,18 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         L.w1b_nblk = c->wino1d >= 2 ? w1b_nblk(Co) : Co / 64 + (Co % 64 > 32 ? 1 : 0);
         w1d_op = w1b_supported(L) && L.w1b_nblk > 0;
     }
+    DevBuf dw8, db8;
+    bool w6_op = false;
+    const int w6_blocks = Co / 64 + (Co % 64 > 32 ? 1 : 0);
+    if (wino == 4 && stride == 1 && c->wino6 && !bf6_op && !w1d_op && w6_blocks > 0 && H * W >= c->wino6_min_pixels) {
+        std::vector<float> w8(wino6_wpk_floats(chunks, Co)), b8((size_t)wino6_nblk(Co) * 64);
+        wino6_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w8.data(), b8.data());
+        CHK(dw8.alloc(w8.size())); CHK(db8.alloc(b8.size()));
+        HIPCHK(hipMemcpy(dw8.p, w8.data(), w8.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(db8.p, b8.data(), b8.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.wpk_w6 = dw8.p; L.bias_w6 = db8.p;
+        w6_op = wino6_supported(L);
+    }
 #if B2F_EXPERIMENTS
     if (wino == 4 && c->wino2_split) {
         std::vector<float> wps(wino2s_wpk_floats(chunks, nblk));
@@ -1528,6 +1574,10 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     else if (w1d_op) {
         HIPCHK(launch_conv3x3_w1b(L, c->stream));
         if (L.w1b_nblk < w1b_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));
+    }
+    else if (w6_op) {
+        HIPCHK(launch_conv3x3_wino6(L, 0, w6_blocks, c->stream));
+        if (w6_blocks < wino6_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));
     }
     else if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));

@@ -73,6 +73,8 @@ struct ConvLaunch {
     const void *wpk_s2b = nullptr;     // stride-2 loader / consumer kernel on the bf16 pipe (b2f_s2b.hip): its split weights, or null
     const float *bias_s2b = nullptr;   // ... and its bias, padded to tiles of 32 outputs
     int w1b_nblk = 0;                  // ... n-blocks of 64 outputs it computes (the first ones; 0 = all)
+    const void *wpk_w6 = nullptr;      // Winograd F(6x6) kernel (b2f_wino6.hip): its weights, or null
+    const float *bias_w6 = nullptr;    // ... and its bias, padded to blocks of 64 outputs
 };
 hipError_t launch_conv3x3(const ConvLaunch &p, hipStream_t s);
 // floats needed for the packed weights of a conv with `cin_chunks` K-chunks
@@ -110,6 +112,13 @@ hipError_t launch_conv3x3_w1b(const ConvLaunch &p, hipStream_t s);
 int w1b_nblk(int cout);
 size_t w1b_wpk_floats(int cin_chunks, int cout);
 void w1b_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
+// stride-1 layers as Winograd F(6x6,3x3) on the fp32 MFMA (b2f_wino6.hip): blocks of 16 tiles x 64 outputs, transformed input in registers;
+// weights [n-block of 64][chunk][row a 8][step 16][lane 64][4]
+bool wino6_supported(const ConvLaunch &p);
+hipError_t launch_conv3x3_wino6(const ConvLaunch &p, int nb0, int nblk, hipStream_t s);   // n-blocks [nb0, nb0 + nblk)
+int wino6_nblk(int cout);
+size_t wino6_wpk_floats(int cin_chunks, int cout);
+void wino6_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // 16 -> 16 (stride 1) + 16 -> 32 (stride 2), both with LeakyReLU(0.2), as ONE streaming kernel on the bf16 pipe (b2f_head.hip): the
 // 16-channel map between them stays in LDS.  Weights: the c16 / c16s2 packings.
 struct HeadLaunch {
