@@ -68,6 +68,11 @@ __device__ __host__ constexpr int colpos(int p) { return (p % 6) * 9 + p / 6; }
 __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6) + 1; }
 }  // namespace wino6
 
+// Profiling only (results are wrong): -DW6_ABLATE=bits, 1 no input transform, 2 no raw staging, 4 no weight loads, 8 no MFMAs, 16 no period barrier,
+// 32 no output rounds (reads, transform, stores), 64 no in-register output transform + dump, 128 every item loads the same patch (L2-resident)
+#ifndef W6_ABLATE
+#define W6_ABLATE 0
+#endif
 #ifndef W6_RING
 #define W6_RING 8      // slots of the weight ring (power of two): loads run W6_RING - 1 steps ahead
 #endif
@@ -125,7 +130,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
     for (int ps = 0; ps < NT / 2; ++ps) {
         if (ps > 0) W6_LDS_BARRIER();           // the previous pass's reads are over
 #pragma unroll
-        for (int mtp = 0; mtp < 2; ++mtp) {
+        for (int mtp = 0; mtp < ((W6_ABLATE & 64) ? 0 : 2); ++mtp) {
             const int mt = 2 * ps + mtp;
             const int quad = mtp * 4 + q4;
             char *dp = smem + X_OFF + (wave * 6) * XPS + t16 * 128 + ((quad ^ (t16 & 7)) * 16);
@@ -155,7 +160,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
         const f32x2 pK7 = {par ? 1.f : 0.f, 0.f};                               // weight of M7 in the last row
         const int xe_off = (par ? 7 : 0) * 6 * XPS;
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
+        for (int rr = 0; rr < ((W6_ABLATE & 32) ? 0 : 3); ++rr) {
             const int idx = (tid & 255) + 256 * rr;                             // 768 items of this parity
             const int quad = idx & 7, xl = (idx >> 3) & 1, mm = idx >> 4;       // mm in 0..47
             const int tyy = mm >= 24 ? 1 : 0, x2 = mm - 24 * tyy;
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
 #define W6_BASES(img_, ox0_, oy0_, b0_, b1_)                                                        \
     do {                                                                                            \
         const long long o__ = ((long long)((oy0_) - 1) * p.W + ((ox0_) - 1)) * p.seg[0].pix_stride; \
-        b0_ = p.seg[0].ptr + ((long long)(img_) * p.seg[0].img_stride + o__);                       \
-        b1_ = p.seg[1].ptr + ((long long)(img_) * p.seg[1].img_stride + o__);                       \
+        b0_ = p.seg[0].ptr + ((W6_ABLATE & 128) ? 0 : ((long long)(img_) * p.seg[0].img_stride + o__)); \
+        b1_ = p.seg[1].ptr + ((W6_ABLATE & 128) ? 0 : ((long long)(img_) * p.seg[1].img_stride + o__)); \
     } while (0)
     const float *ld_b0, *ld_b1, *nxt_b0, *nxt_b1;                            // load side's item / the block's next item
     f32x4 sr[3];
@@ -385,24 +390,23 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         const f32x2 *rd__ = raw2 + ((PP_) ^ 1) * SLOT_F2;                                           \
         f32x2 *wr__ = raw2 + (PP_) * SLOT_F2;                                                       \
         _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                         \
-            if (st >= 1 && st <= 8) W6_ROW_FMA(st - 1);                                             \
-            if (st >= 12) W6_COLPASS(st - 12, (PP_) ^ 1);                                 \
+            if (st >= 1 && st <= 8 && !(W6_ABLATE & 1)) W6_ROW_FMA(st - 1);                         \
+            if (st >= 12 && !(W6_ABLATE & 1)) W6_COLPASS(st - 12, (PP_) ^ 1);                       \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            W6_MFMA(PP_, st, 0);                                                                    \
+            if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 0);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            if (st <= 7) W6_ROW_READ(st, rd__);                                                     \
-            if (st == 9) W6_RAW_WRITE(wr__);                                                       \
+            if (st <= 7 && !(W6_ABLATE & 1)) W6_ROW_READ(st, rd__);                                 \
+            if (st == 9 && !(W6_ABLATE & 2)) W6_RAW_WRITE(wr__);                                    \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            W6_MFMA(PP_, st, 1);                                                                    \
+            if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 1);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            W6_B_LOAD(st + W6_RING - 1);                                                                      \
-            if (st == 10) W6_LOAD_STREAM();                                                         \
+            if (!(W6_ABLATE & 4)) W6_B_LOAD(st + W6_RING - 1);                                      \
+            if (st == 10 && !(W6_ABLATE & 2)) W6_LOAD_STREAM();                                     \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            W6_MFMA(PP_, st, 2);                                                                    \
-            W6_MFMA(PP_, st, 3);                                                                    \
+            if (!(W6_ABLATE & 8)) { W6_MFMA(PP_, st, 2); W6_MFMA(PP_, st, 3); }                     \
             __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
-        W6_LDS_BARRIER();                                                                           \
+        if (!(W6_ABLATE & 16)) W6_LDS_BARRIER();                                                    \
     } while (0)
 
     // ---- first item: prologue ----
