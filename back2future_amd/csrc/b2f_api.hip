@@ -193,7 +193,7 @@ int pack_all(b2f_ctx *c, const float *flat)
             p.b_off7 = total;
             total += (size_t)s2b_ntiles(d.co) * 32;
         }
-        if (p.wino == 4 && c->wino6 && d.co >= 64 - 31) {   // only while the option reads it; layers whose one block has <= 32 outputs never use it
+        if (p.wino == 4 && c->wino6) {   // only while the option reads it (as the other optional packings)
             total = (total + 3) & ~(size_t)3;
             p.w_off8 = total;
             total += wino6_wpk_floats(chunks, d.co);
@@ -453,9 +453,8 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
         L.w1b_nblk = w1d_blocks;
         w1d = w1b_supported(L);
     }
-    // wino6 = 1: the n-blocks with more than 32 real outputs on the F(6x6) kernel, a last block of <= 32 outputs on the F(4x4) single-N-tile kernel
-    const int w6_blocks = p.cout / 64 + (p.cout % 64 > 32 ? 1 : 0);
-    bool w6 = !bf6 && !w1d && mode == 4 && stride == 1 && c->wino6 && p.w_off8 && w6_blocks > 0 && H * W >= c->wino6_min_pixels;
+    // wino6 = 1: Winograd F(6x6) (blocks of 64 outputs, a last block of 32 when the outputs are <= 32 mod 64)
+    bool w6 = !bf6 && !w1d && mode == 4 && stride == 1 && c->wino6 && p.w_off8 && H * W >= c->wino6_min_pixels;
     if (w6) {
         L.wpk_w6 = c->wpk_dev + p.w_off8; L.bias_w6 = c->wpk_dev + p.b_off8;
         w6 = wino6_supported(L);
@@ -476,10 +475,7 @@ int run_conv(b2f_ctx *c, hipStream_t s, bool cap, int conv_id, const ConvSeg *se
         HIPCHK(launch_conv3x3_w1b(L, s));
         if (w1d_blocks < w1b_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
     }
-    else if (w6) {
-        HIPCHK(launch_conv3x3_wino6(L, 0, w6_blocks, s));
-        if (w6_blocks < wino6_nblk(p.cout)) HIPCHK(launch_conv3x3_wino4_rem(L, s));
-    }
+    else if (w6) HIPCHK(launch_conv3x3_wino6(L, s));
     else if (mode == 4) HIPCHK(launch_conv3x3_wino4(L, s));
     else if (mode == 1) HIPCHK(launch_conv_narrow2(L, s));
     else if (mode == 3) HIPCHK(launch_conv3x3_c16(L, s));
@@ -1550,8 +1546,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
     }
     DevBuf dw8, db8;
     bool w6_op = false;
-    const int w6_blocks = Co / 64 + (Co % 64 > 32 ? 1 : 0);
-    if (wino == 4 && stride == 1 && c->wino6 && !bf6_op && !w1d_op && w6_blocks > 0 && H * W >= c->wino6_min_pixels) {
+    if (wino == 4 && stride == 1 && c->wino6 && !bf6_op && !w1d_op && H * W >= c->wino6_min_pixels) {
         std::vector<float> w8(wino6_wpk_floats(chunks, Co)), b8((size_t)wino6_nblk(Co) * 64);
         wino6_pack_weights(wt, bias, Co, Ci, nullptr, chunks, w8.data(), b8.data());
         CHK(dw8.alloc(w8.size())); CHK(db8.alloc(b8.size()));
@@ -1575,10 +1570,7 @@ int b2f_op_conv3x3(b2f_ctx *c, const float *x, int B, int Ci, int H, int W, cons
         HIPCHK(launch_conv3x3_w1b(L, c->stream));
         if (L.w1b_nblk < w1b_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));
     }
-    else if (w6_op) {
-        HIPCHK(launch_conv3x3_wino6(L, 0, w6_blocks, c->stream));
-        if (w6_blocks < wino6_nblk(Co)) HIPCHK(launch_conv3x3_wino4_rem(L, c->stream));
-    }
+    else if (w6_op) HIPCHK(launch_conv3x3_wino6(L, c->stream));
     else if (wino == 4) HIPCHK(launch_conv3x3_wino4(L, c->stream));
     else if (wino == 1) HIPCHK(launch_conv_narrow2(L, c->stream));
     else if (wino == 3) HIPCHK(launch_conv3x3_c16(L, c->stream));

@@ -248,8 +248,8 @@ struct b2f_ctx {
                                    // split packing: setting it > 0 packs it); 0 = all on the fp32 MFMA
     int wino4_split = 0;           // F(4x4) layers with two full N tiles per block: 1 = on the bf16 matrix pipe with exactly split fp32 operands
                                    // (b2f_wino4s.hip; fp32-level accuracy, measured no faster: profiles/r04_wino4s_notes.txt), 0 = on the fp32 MFMA
-    int wino6 = 0;                 // F(4x4)-class layers on maps of at least wino6_min_pixels pixels: 1 = Winograd F(6x6,3x3) on the fp32 MFMA (csrc/b2f_wino6.hip) for the
-                                   // blocks of 64 outputs with more than 32 real ones; a last block of <= 32 outputs stays on the F(4x4) single-N-tile kernel
+    int wino6 = 0;                 // F(4x4)-class layers on maps of at least wino6_min_pixels pixels: 1 = Winograd F(6x6,3x3) on the fp32 MFMA (csrc/b2f_wino6.hip):
+                                   // blocks of 64 outputs, a last block of 32 when the outputs are <= 32 mod 64
     int wino6_min_pixels = 16384;  // ... below that the F(4x4) kernel (items of 12 x 48 pixels quantise small maps badly)
     int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
                                    // Winograd F(4,3) on the bf16 matrix pipe with exactly split fp32 operands, loader / consumer persistent blocks

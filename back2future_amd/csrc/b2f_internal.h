@@ -113,9 +113,9 @@ int w1b_nblk(int cout);
 size_t w1b_wpk_floats(int cin_chunks, int cout);
 void w1b_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);
 // stride-1 layers as Winograd F(6x6,3x3) on the fp32 MFMA (b2f_wino6.hip): blocks of 16 tiles x 64 outputs, transformed input in registers;
-// weights [n-block of 64][chunk][row a 8][step 16][lane 64][4]
+// weights [n-block of 64][chunk][row a 8][step 16][lane 64][4] (a last block of <= 32 outputs: half of that)
 bool wino6_supported(const ConvLaunch &p);
-hipError_t launch_conv3x3_wino6(const ConvLaunch &p, int nb0, int nblk, hipStream_t s);   // n-blocks [nb0, nb0 + nblk)
+hipError_t launch_conv3x3_wino6(const ConvLaunch &p, hipStream_t s);   // blocks of 64 outputs, then one of 32 when the outputs are <= 32 mod 64
 int wino6_nblk(int cout);
 size_t wino6_wpk_floats(int cin_chunks, int cout);
 void wino6_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk);

@@ -208,7 +208,11 @@ template <int NT>
 __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
 {
     using namespace wino6;
-    static_assert(NT == 4, "64 outputs per block");
+    static_assert(NT == 4 || NT == 2, "64 or 32 outputs per block");
+    constexpr int NSTEP = 4 * NT;           // steps of four MFMAs per chunk: 16 (step = (b, K step), the four output tiles) or 8 (step = b: 2 K steps x 2 output tiles)
+    constexpr int SPS = 16 / NSTEP;         // slots of side work per step (the transform of a chunk is 16 slots)
+    constexpr int LAG = SPS;                // slots between the reads of a column and its FMA chain (32-output blocks: two, from a second register set)
+    constexpr int UCN = UC * NT / 4;        // bytes of weights per chunk of this block form
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x2 *raw2 = reinterpret_cast<f32x2 *>(smem);
 
@@ -324,22 +328,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     // ---- input transform: column col_ of the row combination (reads, then the 5-FMA chain), and the column pass in four parts ----
     f32x2 V[2][8];      // B operands of the MFMAs: V[parity][b] = (K step 0 | K step 1)
     f32x2 R[8];         // (B^T d)[a][0..7]
-    f32x2 dq[6];
+    f32x2 dq[SPS][6];
 #define W6_ROW_READ(col_, rd_)                                                                      \
     do {                                                                                            \
         const f32x2 *r__ = (rd_) + cj(col_);                                                        \
-        dq[0] = r__[t_iA + 6 * RP]; dq[1] = r__[t_iA + 2 * RP]; dq[2] = r__[t_iA + 4 * RP];      \
-        dq[3] = r__[t_iB + 1 * RP]; dq[4] = r__[t_iB + 3 * RP]; dq[5] = r__[t_iB + 5 * RP];      \
+        f32x2 *d__ = dq[(col_) & (SPS - 1)];                                                        \
+        d__[0] = r__[t_iA + 6 * RP]; d__[1] = r__[t_iA + 2 * RP]; d__[2] = r__[t_iA + 4 * RP];      \
+        d__[3] = r__[t_iB + 1 * RP]; d__[4] = r__[t_iB + 3 * RP]; d__[5] = r__[t_iB + 5 * RP];      \
     } while (0)
 #define W6_ROW_FMA(col_)                                                                            \
     do {                                                                                            \
         f32x2 t__;                                                                                  \
-        W6_PK_FMA(t__, pc12, LO, dq[1], dq[0]);                                                     \
-        W6_PK_FMA_ACC(t__, pc12, HI, dq[2]);                                                        \
-        W6_PK_FMA_ACC(t__, pc34, LO, dq[3]);                                                        \
-        W6_PK_FMA_ACC(t__, pc34, HI, dq[4]);                                                        \
-        W6_PK_FMA_ACC(t__, pc5x, LO, dq[5]);                                                        \
-        R[col_] = t__;                                                                              \
+        const f32x2 *d__ = dq[(col_) & (SPS - 1)];                                                  \
+        W6_PK_FMA(t__, pc12, LO, d__[1], d__[0]);                                                   \
+        W6_PK_FMA_ACC(t__, pc12, HI, d__[2]);                                                       \
+        W6_PK_FMA_ACC(t__, pc34, LO, d__[3]);                                                       \
+        W6_PK_FMA_ACC(t__, pc34, HI, d__[4]);                                                       \
+        W6_PK_FMA_ACC(t__, pc5x, LO, d__[5]);                                                       \
+        R[(col_) & 7] = t__;                                                                        \
     } while (0)
     const f32x2 qA = {5.25f, -4.25f}, qB = {.25f, -1.25f}, qC = {.5f, -2.5f}, qD = {2.f, 4.f}, qE = {-5.f, -5.f};
 #define W6_COLPASS(part_, vp_)                                                                      \
@@ -363,47 +369,71 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         }                                                                                           \
     } while (0)
 
-    // ---- weights: [n-block][chunk][wave row a][step = 2 b + s][lane][4 output tiles]: lane (co = lane & 15, kk = lane >> 4) holds
-    // U[xi = 8a + b][co 16 mt + (lane & 15)][channel 2 kk + s], mt = 0..3, as one 16-byte load per step; 8-slot ring, seven steps ahead ----
+    // ---- weights: one 16-byte load per step feeds its four MFMAs; 8-slot ring, seven steps ahead.
+    //   64-output blocks  [n-block][chunk][wave row a][step = 2 b + s][lane][4 output tiles]: lane (co = lane & 15, kk = lane >> 4) holds
+    //                     U[xi = 8a + b][co 16 mt + (lane & 15)][channel 2 kk + s], mt = 0..3
+    //   32-output block   [chunk][wave row a][step = b][lane][s 2][mt 2]   (the last block of a layer whose outputs are <= 32 mod 64) ----
     f32x4 bq[W6_RING];
     f32x4 acc[8][NT];
-    const unsigned b_voff = (unsigned)lane * 16u + (unsigned)wave * (unsigned)UW;
+    const unsigned b_voff = (unsigned)lane * 16u + (unsigned)wave * (unsigned)(UW * NT / 4);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wpk), 0, 0x7fffffff, 0x00020000);
     int bo_c, bo_n;                                                          // byte offsets of the compute side's chunk and of the chunk that follows it
 #define W6_B_LOAD(u_)                                                                               \
     do {                                                                                            \
-        const int o__ = (u_) < 16 ? bo_c + (u_) * 1024 : bo_n + ((u_) - 16) * 1024;                 \
+        const int o__ = (u_) < NSTEP ? bo_c + (u_) * 1024 : bo_n + ((u_) - NSTEP) * 1024;           \
         bq[(u_) & (W6_RING - 1)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_voff, o__, 0)); \
     } while (0)
-#define W6_MFMA(pp_, st_, mt_)                                                                      \
-    acc[(st_) >> 1][mt_] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[(st_) & (W6_RING - 1)][mt_], V[pp_][(st_) >> 1][(st_) & 1], acc[(st_) >> 1][mt_], 0, 0, 0)
+    // MFMA i of step st_: (b, K step s, output tile mt) = (st >> 1, st & 1, i) resp. (st, i >> 1, i & 1)
+#define W6_MFMA(pp_, st_, i_)                                                                       \
+    do {                                                                                            \
+        const int b__ = NT == 4 ? (st_) >> 1 : (st_), s__ = NT == 4 ? (st_) & 1 : (i_) >> 1, mt__ = NT == 4 ? (i_) : (i_) & 1;     \
+        acc[b__][mt__] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[(st_) & (W6_RING - 1)][i_], V[pp_][b__][s__], acc[b__][mt__], 0, 0, 0); \
+    } while (0)
 
-    // One chunk period (parity PP_): the 64 MFMAs of the compute side's chunk on V[PP_], and between them, pinned by scheduling barriers --
-    //   steps 0..7   the reads of column st of the NEXT chunk's row combination (ring slot PP_ ^ 1), steps 1..8 its FMA chain,
-    //   steps 9..12  the column pass -> V[PP_ ^ 1],
-    //   step 13      the raw patch two chunks ahead (loaded a period ago) -> ring slot PP_,   step 14   the loads of the patch three chunks ahead,
-    //   every step   one weight load, seven steps ahead (after MFMA 0: the slot it overwrites was last read by the previous step).
-    // VALU work first in a step (its operands were read a step ago), memory instructions between the MFMAs.  One barrier per period: what it
-    // orders was written at least a step before it and is read a whole period later.
+    // One chunk period (parity PP_): the MFMAs of the compute side's chunk on V[PP_], and between them, pinned by scheduling barriers, the 16
+    // slots of side work --
+    //   slots 0..7      the reads of column k of the NEXT chunk's row combination (ring slot PP_ ^ 1); slots LAG..7 + LAG its FMA chain,
+    //   slots 12..15    the column pass -> V[PP_ ^ 1] (late: the registers of the V[PP_] pairs already multiplied are free by then),
+    //   slot 9          the raw patch two chunks ahead (loaded a period ago) -> ring slot PP_,   slot 10   the loads of the patch three chunks ahead,
+    //   every step      one weight load, seven steps ahead (after MFMA 0: the slot it overwrites was last read by the previous step).
+    // VALU work first (its operands were read LAG slots ago), memory instructions between the MFMAs.  One barrier per period: what it orders
+    // was written at least a step before it and is read a whole period later.
+#define W6_SLOT_VALU(k_, PP_)                                                                       \
+    do {                                                                                            \
+        if ((k_) >= LAG && (k_) < 8 + LAG && !(W6_ABLATE & 1)) W6_ROW_FMA((k_) - LAG);              \
+        if ((k_) >= 12 && !(W6_ABLATE & 1)) W6_COLPASS((k_) - 12, (PP_) ^ 1);                       \
+    } while (0)
+#define W6_SLOT_LDS(k_, PP_)                                                                        \
+    do {                                                                                            \
+        if ((k_) <= 7 && !(W6_ABLATE & 1)) W6_ROW_READ((k_), rd__);                                 \
+        if ((k_) == 9 && !(W6_ABLATE & 2)) W6_RAW_WRITE(wr__);                                      \
+    } while (0)
+#define W6_SLOT_VMEM(k_) do { if ((k_) == 10 && !(W6_ABLATE & 2)) W6_LOAD_STREAM(); } while (0)
 #define W6_PERIOD(PP_)                                                                              \
     do {                                                                                            \
         const f32x2 *rd__ = raw2 + ((PP_) ^ 1) * SLOT_F2;                                           \
         f32x2 *wr__ = raw2 + (PP_) * SLOT_F2;                                                       \
-        _Pragma("unroll") for (int st = 0; st < 16; ++st) {                                         \
-            if (st >= 1 && st <= 8 && !(W6_ABLATE & 1)) W6_ROW_FMA(st - 1);                         \
-            if (st >= 12 && !(W6_ABLATE & 1)) W6_COLPASS(st - 12, (PP_) ^ 1);                       \
+        _Pragma("unroll") for (int st = 0; st < NSTEP; ++st) {                                      \
+            W6_SLOT_VALU(SPS * st, PP_);                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 0);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            if (st <= 7 && !(W6_ABLATE & 1)) W6_ROW_READ(st, rd__);                                 \
-            if (st == 9 && !(W6_ABLATE & 2)) W6_RAW_WRITE(wr__);                                    \
+            W6_SLOT_LDS(SPS * st, PP_);                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 1);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            if (SPS == 2) W6_SLOT_VALU(2 * st + 1, PP_);                                            \
             if (!(W6_ABLATE & 4)) W6_B_LOAD(st + W6_RING - 1);                                      \
-            if (st == 10 && !(W6_ABLATE & 2)) W6_LOAD_STREAM();                                     \
+            W6_SLOT_VMEM(SPS * st);                                                                 \
+            if (SPS == 2) W6_SLOT_VMEM(2 * st + 1);                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            if (!(W6_ABLATE & 8)) { W6_MFMA(PP_, st, 2); W6_MFMA(PP_, st, 3); }                     \
+            if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 2);                                              \
+            if (SPS == 2) {                                                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+                W6_SLOT_LDS(2 * st + 1, PP_);                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            }                                                                                       \
+            if (!(W6_ABLATE & 8)) W6_MFMA(PP_, st, 3);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                      \
         }                                                                                           \
         if (!(W6_ABLATE & 16)) W6_LDS_BARRIER();                                                    \
@@ -418,8 +448,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     has_next = false;                                                        // no switch inside the prologue (nchunks >= 4)
     nxt_nb = cur_nb; nxt_img = cur_img; nxt_ox0 = cur_ox0; nxt_oy0 = cur_oy0;
     mk_n[0] = mk[0]; mk_n[1] = mk[1]; mk_n[2] = mk[2];
-    bo_c = cur_nb * nchunks * UC;
-    bo_n = bo_c + UC;
+    bo_c = cur_nb * nchunks * UC;            // (a 32-output block is the layer's last: every block before it has the full size)
+    bo_n = bo_c + UCN;
     {
         W6_LOAD_STREAM();                                                    // chunk 0
         f32x4 keep[3];
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     // after an item's last chunk -- the output stage and the step to the block's next item
 #define W6_RUN(PP_)                                                                                 \
     do {                                                                                            \
-        bo_n = c + 1 < nchunks ? bo_c + UC : (has_next ? nxt_nb : cur_nb) * nchunks * UC;           \
+        bo_n = c + 1 < nchunks ? bo_c + UCN : (has_next ? nxt_nb : cur_nb) * nchunks * UC;          \
         W6_PERIOD(PP_);                                                                             \
         bo_c = bo_n;                                                                                \
         if (++c == nchunks) {                                                                       \
@@ -481,6 +511,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
 #undef W6_RUN
 #undef W6_ITEM_START
 #undef W6_PERIOD
+#undef W6_SLOT_VMEM
+#undef W6_SLOT_LDS
+#undef W6_SLOT_VALU
 #undef W6_MFMA
 #undef W6_B_LOAD
 #undef W6_COLPASS
@@ -507,17 +540,16 @@ bool wino6_supported(const ConvLaunch &p)
     return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 2147483648.0;   // 32-bit byte offsets inside a plane
 }
 
-// the n-blocks [nb0, nb0 + nblk) of 64 outputs each
-hipError_t launch_conv3x3_wino6(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
+template <int NT>
+static hipError_t launch_wino6_t(const ConvLaunch &p, int nb0, int nblk, hipStream_t s)
 {
     using namespace wino6;
-    if (!wino6_supported(p) || !p.wpk_w6 || nblk <= 0) return hipErrorInvalidValue;
     static bool attr_done_dev[64] = {false};
     static int n_cu_dev[64] = {0};
     bool &attr_done = attr_done_dev[attr_slot()];
     int &n_cu = n_cu_dev[attr_slot()];
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino6<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_wino6<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
@@ -534,16 +566,32 @@ hipError_t launch_conv3x3_wino6(const ConvLaunch &p, int nb0, int nblk, hipStrea
     const long items = (long)((p.Wo + OW - 1) / OW) * ((p.Ho + OH - 1) / OH) * p.nimg * nblk;
     const int pcap = p.w4_persist > 1 ? p.w4_persist : n_cu;               // (tests: exactly that many blocks)
     const int grid = (int)(items < pcap ? items : pcap);
-    hipLaunchKernelGGL((conv3x3_wino6<4>), dim3((unsigned)grid), dim3(512), LDS_BYTES, s, q);
+    hipLaunchKernelGGL((conv3x3_wino6<NT>), dim3((unsigned)grid), dim3(512), LDS_BYTES, s, q);
     return hipGetLastError();
+}
+
+// the whole layer: blocks of 64 outputs, then -- when the outputs are <= 32 mod 64 -- one block of 32
+hipError_t launch_conv3x3_wino6(const ConvLaunch &p, hipStream_t s)
+{
+    if (!wino6_supported(p) || !p.wpk_w6) return hipErrorInvalidValue;
+    const int rem = p.cout % 64, n64 = p.cout / 64 + (rem > 32 ? 1 : 0);
+    hipError_t e = hipSuccess;
+    if (n64 > 0) e = launch_wino6_t<4>(p, 0, n64, s);
+    if (e == hipSuccess && rem > 0 && rem <= 32) e = launch_wino6_t<2>(p, p.cout / 64, 1, s);
+    return e;
 }
 
 int wino6_nblk(int cout) { return (cout + 63) / 64; }
 
-size_t wino6_wpk_floats(int cin_chunks, int cout) { return (size_t)wino6_nblk(cout) * cin_chunks * (wino6::UC / 4); }
+size_t wino6_wpk_floats(int cin_chunks, int cout)
+{
+    const int rem = cout % 64;
+    return (size_t)(cout / 64) * cin_chunks * (wino6::UC / 4) + (rem > 32 ? (size_t)cin_chunks * (wino6::UC / 4) : rem > 0 ? (size_t)cin_chunks * (wino6::UC / 8) : 0);
+}
 
-// U = G g G^T in double, rounded once to fp32; packed [n-block][chunk][a 8][step 2 b + s][lane 64][mt 4]:
-// lane (co = 64 nb + 16 mt + (lane & 15), input channel = 8 chunk + 2 (lane >> 4) + s), xi = 8 a + b
+// U = G g G^T in double, rounded once to fp32 (row a = 0 negated: wave 0 forms -(B^T d)[0]).  Blocks of 64 outputs:
+// [n-block][chunk][a 8][step 2 b + s][lane 64][mt 4], lane (co = 64 nb + 16 mt + (lane & 15), input channel = 8 chunk + 2 (lane >> 4) + s), xi = 8 a + b;
+// a last block of <= 32 outputs: [chunk][a 8][b 8][lane 64][s 2][mt 2]
 void wino6_pack_weights(const float *w, const float *b, int Co, int Ci, const int *cin_map, int cin_chunks, float *wpk, float *bpk)
 {
     static const double G[8][3] = {{1, 0, 0},
@@ -564,21 +612,32 @@ void wino6_pack_weights(const float *w, const float *b, int Co, int Ci, const in
                 for (int v = 0; v < 3; ++v) t[a][v] = G[a][0] * gk[0 * 3 + v] + G[a][1] * gk[1 * 3 + v] + G[a][2] * gk[2 * 3 + v];
             for (int a = 0; a < 8; ++a)
                 for (int bq = 0; bq < 8; ++bq)
-                    U[((size_t)co * Ci + ci) * 64 + a * 8 + bq] = (float)(t[a][0] * G[bq][0] + t[a][1] * G[bq][1] + t[a][2] * G[bq][2]);
+                    U[((size_t)co * Ci + ci) * 64 + a * 8 + bq] = (float)(t[a][0] * G[bq][0] + t[a][1] * G[bq][1] + t[a][2] * G[bq][2]) * (a == 0 ? -1.f : 1.f);
         }
-    for (int nbk = 0; nbk < nblk; ++nbk)
+    auto u_at = [&](int co, int k, int xi) -> float {
+        const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
+        return (co < Co && ci >= 0) ? U[((size_t)co * Ci + ci) * 64 + xi] : 0.f;
+    };
+    const size_t blk_floats = (size_t)cin_chunks * (wino6::UC / 4);
+    for (int nbk = 0; nbk < nblk; ++nbk) {
+        float *dst = wpk + (size_t)nbk * blk_floats;
+        const bool small = nbk == Co / 64 && Co % 64 <= 32;                 // (the last block of a layer whose outputs are <= 32 mod 64; Co % 64 > 0 there)
         for (int c = 0; c < cin_chunks; ++c)
             for (int a = 0; a < 8; ++a)
-                for (int st = 0; st < 16; ++st)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const int co = nbk * 64 + mt * 16 + (lane & 15);
-                            const int k = c * kCK + 2 * (lane >> 4) + (st & 1);
-                            const int ci = cin_map ? cin_map[k] : (k < Ci ? k : -1);
-                            float v = 0.f;
-                            if (co < Co && ci >= 0) v = U[((size_t)co * Ci + ci) * 64 + a * 8 + (st >> 1)] * (a == 0 ? -1.f : 1.f);   // wave 0 forms -(B^T d)[0]
-                            wpk[(((((size_t)nbk * cin_chunks + c) * 8 + a) * 16 + st) * 64 + lane) * 4 + mt] = v;
-                        }
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int kk = 2 * (lane >> 4), col = lane & 15;
+                    if (!small) {
+                        for (int st = 0; st < 16; ++st)
+                            for (int mt = 0; mt < 4; ++mt)
+                                dst[((((size_t)c * 8 + a) * 16 + st) * 64 + lane) * 4 + mt] = u_at(nbk * 64 + mt * 16 + col, c * kCK + kk + (st & 1), a * 8 + (st >> 1));
+                    } else {
+                        for (int bq = 0; bq < 8; ++bq)
+                            for (int sk = 0; sk < 2; ++sk)
+                                for (int mt = 0; mt < 2; ++mt)
+                                    dst[((((size_t)c * 8 + a) * 8 + bq) * 64 + lane) * 4 + sk * 2 + mt] = u_at(nbk * 64 + mt * 16 + col, c * kCK + kk + sk, a * 8 + bq);
+                    }
+                }
+    }
     for (int i = 0; i < nblk * 64; ++i) bpk[i] = i < Co ? b[i] : 0.f;
 }
 

@@ -66,14 +66,14 @@ def conv_layers(H, W):
     return out
 
 
-MODE_CLASS = {"W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2",
+MODE_CLASS = {"W6": "conv3x3_wino6", "W4": "conv3x3_wino4", "W2": "conv3x3_wino", "N2": "conv3x3_narrow2", "C16": "conv3x3_c16", "S16": "conv3x3_s2x16", "D1": "conv3x3_s1", "D2": "conv3x3_s2",
               "B16": "conv3x3_c16_bf16", "H16": "conv_head16_bf16", "E1": "conv3x3_s1_bf16", "E2": "conv3x3_s2_bf16", "V1": "conv3x3_w1b", "L2": "conv3x3_s2b"}
 BF16_PIPE = ("conv3x3_c16_bf16", "conv_head16_bf16", "conv3x3_s1_bf16", "conv3x3_s2_bf16", "conv3x3_w1b", "conv3x3_s2b")   # split-operand kernels on the bf16 matrix pipe: no fp32-MFMA FLOPs
 
 
 def layer_kernels(model, step, torch):
     """Kernel class of every conv layer AS THE LIBRARY RAN IT: one eager pass with option profile_layers, whose rows are named
-    conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
+    conv<mode>_<cin>to<cout>_<H>x<W> by b2f_api.hip:run_conv (mode W6 = Winograd F(6x6) [a last block of <= 32 outputs on the F(4x4) kernel], W4 = Winograd F(4x4), W2 = F(2x2), N2 = 2-output VALU kernel,
     C16 = 16 -> 16 kernel, S16 = 16 -> 32 stride-2 kernel, D1 / D2 = direct kernel stride 1 / 2, B16 = the 16 -> 16 layer on the bf16 pipe,
     E1 / E2 = direct kernel on the bf16 pipe stride 1 / 2, H16 = the fused head: 16 -> 16 and 16 -> 32 stride 2 in one kernel on the bf16 pipe, one row for both layers).
     Returns {(cin_padded, cout, H_in, W_in): class}."""
@@ -90,7 +90,7 @@ def layer_kernels(model, step, torch):
     import re
     out = {}
     for name, (ms, n) in rows.items():
-        m = re.match(r"^conv(W4|W2|N2|C16|S16|D1|D2|B16|H16|E1|E2|V1|L2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
+        m = re.match(r"^conv(W6|W4|W2|N2|C16|S16|D1|D2|B16|H16|E1|E2|V1|L2)_(\d+)to(\d+)_(\d+)x(\d+)$", name)
         if m and n > 0:            # (rows of earlier passes keep their names with zero counts)
             out[(int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))] = MODE_CLASS[m.group(1)]
             if m.group(1) == "H16":  # the fused head also holds the 16 -> 16 layer in front of its 16 -> 32 one
@@ -100,7 +100,7 @@ def layer_kernels(model, step, torch):
 
 def conv_flops_by_kernel(H, W, kernels):
     """Per kernel class and triplet: (algorithmic direct-convolution FLOPs, FLOPs the MFMA pipe executes); `kernels` = the
-    library's own choice per layer (layer_kernels).  Executed: F(4x4) 36/16 MACs per output and channel pair, F(2x2) 16/4, direct 9;
+    library's own choice per layer (layer_kernels).  Executed: F(6x6) 64/36 MACs per output and channel pair, F(4x4) 36/16, F(2x2) 16/4, direct 9;
     input channels as conv_layers pads them, outputs to 32 (16 for the 16 -> 16 kernel); VALU kernels 0."""
     alg, exe = {}, {}
     for ci, co, stride, h, w, calls, cip in conv_layers(H, W):
@@ -109,6 +109,9 @@ def conv_flops_by_kernel(H, W, kernels):
         cop = (co + 31) // 32 * 32
         per_out = {"conv3x3_wino4": 36.0 / 16.0, "conv3x3_wino": 16.0 / 4.0}.get(k, 9.0)
         e = 2.0 * per_out * cip * cop
+        if k == "conv3x3_wino6":   # blocks of 64 outputs with more than 32 real ones at 64/36 MACs per output, a last block of <= 32 outputs on F(4x4)
+            c6 = 64 * (co // 64 + (1 if co % 64 > 32 else 0))
+            e = 2.0 * cip * ((64.0 / 36.0) * min(c6, (co + 63) // 64 * 64) + (36.0 / 16.0) * max(0, cop - c6))
         if k in ("conv_first", "conv3x3_narrow2") or k in BF16_PIPE:
             e = 0.0
         if k == "conv3x3_c16":
@@ -496,8 +499,8 @@ def main():
             # `frac` is the utilisation of the matrix pipe: the FLOPs the MFMAs of this kernel really execute (Winograd
             # F(4x4): 36/16 MACs per output and channel pair, channel padding included) / its time / the fp32 MFMA peak.
             # The direct-convolution-equivalent rate (4x the MACs) is reported separately as `effective_vs_direct`.
-            out["roofline"] = {"kernel": "%s (Winograd F(4x4,3x3) on the fp32 MFMA; %.0f %% of the profiled step)" % (dom, 100.0 * d_ms / (1e3 * prof_dt / args.steps))
-                               if dom == "conv3x3_wino4" else dom,
+            out["roofline"] = {"kernel": "%s (Winograd %s on the fp32 MFMA; %.0f %% of the profiled step)" % (dom, "F(6x6,3x3)" if dom == "conv3x3_wino6" else "F(4x4,3x3)", 100.0 * d_ms / (1e3 * prof_dt / args.steps))
+                               if dom in ("conv3x3_wino4", "conv3x3_wino6") else dom,
                                "bound": "mfma", "achieved": ea, "peak": 157.3, "unit": "TFLOP/s", "frac": ea / 157.3,
                                "executed_flop_per_step": d_exe,
                                "effective_vs_direct": {"achieved": a, "unit": "TFLOP/s of direct-convolution FLOPs (2*9*Ci*Co per output)",
