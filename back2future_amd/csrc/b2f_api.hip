@@ -521,7 +521,7 @@ struct Outs {
 // complete model:forward of models/pwc.lua.
 int forward_impl(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, int in_kind, const Plan &P, const Outs &O)
 {
-    c->cur_batch = P.B;
+    c->cur_batch = c->req_batch > 0 ? c->req_batch : P.B;
     float *A = c->arena;
     const int B = P.B;
     const bool full = P.full, past = c->past_flow && full;
@@ -1203,7 +1203,8 @@ int b2f::forward_device(b2f_ctx *c, const void *dev_in, int in_kind, int B, int 
             HIPCHK(hipDeviceSynchronize());
             drop_graphs(c);
         }
-        const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W};
+        const int req = c->req_batch > 0 ? c->req_batch : B;
+        const GraphKey key = {dev_in, dev_flow, dev_occ, dev_est3, in_kind, B, H, W, (c->adaptive_kernels > 0 || (c->adaptive_kernels < 0 && req == 1)) ? 1 : 0};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             c->graphs.emplace(key, nullptr);

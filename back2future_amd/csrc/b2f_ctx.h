@@ -55,9 +55,10 @@ struct GraphKey {
     const void *in;
     float *flow, *occ, *est3;
     int kind, B, H, W;
+    int rule;                      // kernel-choice rule the captured launches follow (1 = per launch: a single-triplet request), part of the key
     bool operator<(const GraphKey &o) const
     {
-        return std::tie(in, flow, occ, est3, kind, B, H, W) < std::tie(o.in, o.flow, o.occ, o.est3, o.kind, o.B, o.H, o.W);
+        return std::tie(in, flow, occ, est3, kind, B, H, W, rule) < std::tie(o.in, o.flow, o.occ, o.est3, o.kind, o.B, o.H, o.W, o.rule);
     }
 };
 
@@ -228,7 +229,9 @@ struct b2f_ctx {
                                    // level 7 of a full-HD triplet: 64 tiles per launch at batch 16 -- 0.25 -> 0.20 ms for its six layers)
     int wino4_min_pixels = 4096;   // F(4x4) for maps of at least this many pixels, F(2x2) below: depends on the map size
                                    // only, so a triplet's result does not depend on the batch it is computed in
-    int cur_batch = 0;             // triplets of the forward pass being issued (run_conv's per-launch rule for single-triplet calls)
+    int cur_batch = 0;             // triplets of the REQUEST the forward pass being issued belongs to (run_conv's per-launch rule for single-triplet calls)
+    int req_batch = 0;             // set by the host-buffer entry points to the caller's n while they issue their sub-batches (0: a forward call's own B):
+                                   // the kernel choice follows the caller's request, so a triplet's bits do not depend on its position in a batch
     int adaptive_kernels = -1;     // -1 (default): per launch for single-triplet calls, by map size for batches; 0: by map size always;
                                    // 1: choose the Winograd variant per launch by block rounds on the 256 CUs (faster for
                                    // single triplets / small batches; results then depend on the batch size at 1e-6 level)
@@ -248,7 +251,7 @@ struct b2f_ctx {
                                    // split packing: setting it > 0 packs it); 0 = all on the fp32 MFMA
     int wino4_split = 0;           // F(4x4) layers with two full N tiles per block: 1 = on the bf16 matrix pipe with exactly split fp32 operands
                                    // (b2f_wino4s.hip; fp32-level accuracy, measured no faster: profiles/r04_wino4s_notes.txt), 0 = on the fp32 MFMA
-    int wino6 = 0;                 // F(4x4)-class layers on maps of at least wino6_min_pixels pixels: 1 = Winograd F(6x6,3x3) on the fp32 MFMA (csrc/b2f_wino6.hip):
+    int wino6 = 1;                 // F(4x4)-class layers on maps of at least wino6_min_pixels pixels: 1 = Winograd F(6x6,3x3) on the fp32 MFMA (csrc/b2f_wino6.hip):
                                    // blocks of 64 outputs, a last block of 32 when the outputs are <= 32 mod 64
     int wino6_min_pixels = 16384;  // ... below that the F(4x4) kernel (items of 12 x 48 pixels quantise small maps badly)
     int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional

@@ -174,6 +174,7 @@ static int graph_run(b2f_ctx *c, hipStream_t s, bool cap, const void *dev_in, in
     const int L = g.levels, LST = g.l_st(), nd = g.nd();
     const bool past = g.past_flow;
     const int unit = in_kind == B2F_IN_UNIT;
+    c->cur_batch = c->req_batch > 0 ? c->req_batch : B;   // run_conv's kernel rule reads it (as forward_impl sets it for the shipped graph)
     Bump A{dry ? nullptr : c->arena};
     int hh[8], ww[8];
     for (int l = 1; l <= 7; ++l) { hh[l] = H >> (l - 1); ww[l] = W >> (l - 1); }

@@ -109,6 +109,9 @@ int compute_flow_pipeline(b2f_ctx *c, int n, const void *im1, const void *im2, c
     const int fw = W0 - W0 % 64, fh = H0 - H0 % 64;   // back2future.lua:54-67
     if (fw <= 0 || fh <= 0) return fail("b2f_compute_flow: image smaller than 64 pixels");
     CHK(check_shape(1, fh, fw));
+    // the kernel choice of every sub-batch follows the caller's n (a single-triplet request takes the per-launch rule, a batch the map-size
+    // rule -- for ALL its sub-batches, also those of one triplet the ramp and the tail produce)
+    struct ReqBatch { b2f_ctx *c; ReqBatch(b2f_ctx *cc, int nn) : c(cc) { c->req_batch = nn; } ~ReqBatch() { c->req_batch = 0; } } req_guard(c, n);
     HIPCHK(hipSetDevice(c->device));
     const size_t hw0 = (size_t)H0 * W0, hw = (size_t)fh * fw;
     const bool same = (fw == W0 && fh == H0);

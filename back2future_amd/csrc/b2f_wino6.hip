@@ -95,7 +95,7 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 #define W6_PK_SUB(d_, x_, y_) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d_) : "v"(x_), "v"(y_))
 #define W6_PK_ACC(d_, x_) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d_) : "v"(x_))
 
-// ---- output stage of one item: A^T M A, bias, LeakyReLU, stores.  acc[b][mt] = M[8 wave + b][co = 16 mt + 4 (lane >> 4) + r][tile = lane & 15] ----
+// ---- output stage of one item: A^T M A, LeakyReLU, stores (the bias is already in M).  acc[b][mt] = M[8 wave + b][co = 16 mt + 4 (lane >> 4) + r][tile = lane & 15] ----
 // The b direction (8 -> 6) happens in registers -- T[a][j] = sum_b M[a][b] A^T[j][b], the lane holds all eight b of its (tile, outputs) --, the
 // a direction goes through LDS in passes of 32 outputs (two MFMA output tiles): X[a 8][j 6] planes of XPS bytes, a plane = [tile 16][32 outputs]
 // with the 16-byte unit of output quad q of tile t at (q ^ (t & 7)).
@@ -168,7 +168,6 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
             const int tile = tyy * 8 + txx;
             const char *xb = smem + X_OFF + j * XPS + tile * 128 + ((quad ^ (tile & 7)) * 16);
             const int co0 = nb * 64 + ps * 32 + quad * 4;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + ((nb - p.nb0) * 64 + ps * 32 + quad * 4) * 4);
             // even rows: y0 = M0 + s1 + s2 + s3, y2 = s1 + 4 s2 + s3/4, y4 = s1 + 16 s2 + s3/16;  odd: y1 = d1 + 2 d2 + d3/2, y3 = d1 + 8 d2 + d3/8,
             // y5 = d1 + 32 d2 + d3/32 + M7 -- one instruction stream with wave-uniform coefficients, one half (two outputs) of the quad at a time
             f32x2 y[3][2];
@@ -190,7 +189,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
             const bool ok = co0 < p.cout && ox < p.Wo;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                f32x4 v = __builtin_shufflevector(y[i][0], y[i][1], 0, 1, 2, 3) + bias;
+                f32x4 v = __builtin_shufflevector(y[i][0], y[i][1], 0, 1, 2, 3);               // (the bias came through the accumulators: W6_ITEM_START)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaxf(v[k], slope * v[k]);   // LeakyReLU(0.2): v > 0 ? v : 0.2 v  (slope 1: identity)
                 // (the row offset goes into the lane offset, NOT into the scalar offset: behind a 16-byte buffer store with a register soffset hipcc
@@ -336,36 +335,66 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         d__[0] = r__[t_iA + 6 * RP]; d__[1] = r__[t_iA + 2 * RP]; d__[2] = r__[t_iA + 4 * RP];      \
         d__[3] = r__[t_iB + 1 * RP]; d__[4] = r__[t_iB + 3 * RP]; d__[5] = r__[t_iB + 5 * RP];      \
     } while (0)
+    // (one asm statement per chain: between two dependent asm statements hipcc pads an s_nop that the hardware does not need -- VALU results
+    // are interlocked -- 32 of them per chunk)
 #define W6_ROW_FMA(col_)                                                                            \
     do {                                                                                            \
         f32x2 t__;                                                                                  \
         const f32x2 *d__ = dq[(col_) & (SPS - 1)];                                                  \
-        W6_PK_FMA(t__, pc12, LO, d__[1], d__[0]);                                                   \
-        W6_PK_FMA_ACC(t__, pc12, HI, d__[2]);                                                       \
-        W6_PK_FMA_ACC(t__, pc34, LO, d__[3]);                                                       \
-        W6_PK_FMA_ACC(t__, pc34, HI, d__[4]);                                                       \
-        W6_PK_FMA_ACC(t__, pc5x, LO, d__[5]);                                                       \
+        asm volatile("v_pk_fma_f32 %0, %1, %5, %4" W6_SEL3_LO "\n\t"                                \
+                     "v_pk_fma_f32 %0, %1, %6, %0" W6_SEL3_HI "\n\t"                                \
+                     "v_pk_fma_f32 %0, %2, %7, %0" W6_SEL3_LO "\n\t"                                \
+                     "v_pk_fma_f32 %0, %2, %8, %0" W6_SEL3_HI "\n\t"                                \
+                     "v_pk_fma_f32 %0, %3, %9, %0" W6_SEL3_LO                                        \
+                     : "=&v"(t__) : "s"(pc12), "s"(pc34), "s"(pc5x), "v"(d__[0]), "v"(d__[1]), "v"(d__[2]), "v"(d__[3]), "v"(d__[4]), "v"(d__[5])); \
         R[(col_) & 7] = t__;                                                                        \
     } while (0)
     const f32x2 qA = {5.25f, -4.25f}, qB = {.25f, -1.25f}, qC = {.5f, -2.5f}, qD = {2.f, 4.f}, qE = {-5.f, -5.f};
 #define W6_COLPASS(part_, vp_)                                                                      \
     do {                                                                                            \
-        f32x2 P__, Q__, u__;                                                                        \
+        f32x2 P__, Q__;                                                                             \
         if ((part_) == 0) {                                                                         \
-            W6_PK_SUB(P__, R[4], R[2]); W6_PK_SUB(u__, R[0], R[6]); W6_PK_FMA(V[vp_][0], qA, LO, P__, u__); \
-            W6_PK_SUB(Q__, R[3], R[5]); W6_PK_SUB(u__, R[7], R[1]); W6_PK_FMA(V[vp_][7], qA, LO, Q__, u__); \
+            /* V0 = (R0 - R6) + 5.25 (R4 - R2),  V7 = (R7 - R1) + 5.25 (R3 - R5) */                 \
+            asm volatile("v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+                         "v_pk_add_f32 %0, %4, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+                         "v_pk_fma_f32 %0, %12, %2, %0" W6_SEL3_LO "\n\t"                           \
+                         "v_pk_add_f32 %3, %8, %9 neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+                         "v_pk_add_f32 %1, %11, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"                  \
+                         "v_pk_fma_f32 %1, %12, %3, %1" W6_SEL3_LO                                  \
+                         : "=&v"(V[vp_][0]), "=&v"(V[vp_][7]), "=&v"(P__), "=&v"(Q__)               \
+                         : "v"(R[0]), "v"(R[2]), "v"(R[4]), "v"(R[6]), "v"(R[3]), "v"(R[5]), "v"(R[1]), "v"(R[7]), "s"(qA)); \
         } else if ((part_) == 1) {                                                                  \
-            W6_PK_ADD(P__, R[2], R[6]); W6_PK_FMA_ACC(P__, qA, HI, R[4]);                           \
-            W6_PK_ADD(Q__, R[1], R[5]); W6_PK_FMA_ACC(Q__, qA, HI, R[3]);                           \
-            W6_PK_ADD(V[vp_][1], P__, Q__); W6_PK_SUB(V[vp_][2], P__, Q__);                         \
+            /* P = R2 + R6 - 4.25 R4, Q = R1 + R5 - 4.25 R3, V1 = P + Q, V2 = P - Q */              \
+            asm volatile("v_pk_add_f32 %2, %4, %6\n\t"                                              \
+                         "v_pk_fma_f32 %2, %10, %5, %2" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_add_f32 %3, %7, %9\n\t"                                              \
+                         "v_pk_fma_f32 %3, %10, %8, %3" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_add_f32 %0, %2, %3\n\t"                                              \
+                         "v_pk_add_f32 %1, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"                        \
+                         : "=&v"(V[vp_][1]), "=&v"(V[vp_][2]), "=&v"(P__), "=&v"(Q__)               \
+                         : "v"(R[2]), "v"(R[4]), "v"(R[6]), "v"(R[1]), "v"(R[3]), "v"(R[5]), "s"(qA)); \
         } else if ((part_) == 2) {                                                                  \
-            W6_PK_FMA(P__, qB, LO, R[2], R[6]); W6_PK_FMA_ACC(P__, qB, HI, R[4]);                   \
-            W6_PK_MUL(Q__, qC, LO, R[1]); W6_PK_FMA_ACC(Q__, qC, HI, R[3]); W6_PK_FMA_ACC(Q__, qD, LO, R[5]); \
-            W6_PK_ADD(V[vp_][3], P__, Q__); W6_PK_SUB(V[vp_][4], P__, Q__);                         \
+            /* P = R6 + .25 R2 - 1.25 R4, Q = .5 R1 - 2.5 R3 + 2 R5, V3 = P + Q, V4 = P - Q */      \
+            asm volatile("v_pk_fma_f32 %2, %10, %4, %6" W6_SEL3_LO "\n\t"                           \
+                         "v_pk_fma_f32 %2, %10, %5, %2" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_mul_f32 %3, %11, %7" W6_SEL2_LO "\n\t"                               \
+                         "v_pk_fma_f32 %3, %11, %8, %3" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_fma_f32 %3, %12, %9, %3" W6_SEL3_LO "\n\t"                           \
+                         "v_pk_add_f32 %0, %2, %3\n\t"                                              \
+                         "v_pk_add_f32 %1, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"                        \
+                         : "=&v"(V[vp_][3]), "=&v"(V[vp_][4]), "=&v"(P__), "=&v"(Q__)               \
+                         : "v"(R[2]), "v"(R[4]), "v"(R[6]), "v"(R[1]), "v"(R[3]), "v"(R[5]), "s"(qB), "s"(qC), "s"(qD)); \
         } else {                                                                                    \
-            W6_PK_FMA(P__, qD, HI, R[2], R[6]); W6_PK_FMA_ACC(P__, qE, LO, R[4]);                   \
-            W6_PK_MUL(Q__, qD, LO, R[1]); W6_PK_FMA_ACC(Q__, qC, HI, R[3]); W6_PK_FMA_ACC(Q__, qC, LO, R[5]); \
-            W6_PK_ADD(V[vp_][5], P__, Q__); W6_PK_SUB(V[vp_][6], P__, Q__);                         \
+            /* P = R6 + 4 R2 - 5 R4, Q = 2 R1 - 2.5 R3 + .5 R5, V5 = P + Q, V6 = P - Q */           \
+            asm volatile("v_pk_fma_f32 %2, %12, %4, %6" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_fma_f32 %2, %10, %5, %2" W6_SEL3_LO "\n\t"                           \
+                         "v_pk_mul_f32 %3, %12, %7" W6_SEL2_LO "\n\t"                               \
+                         "v_pk_fma_f32 %3, %11, %8, %3" W6_SEL3_HI "\n\t"                           \
+                         "v_pk_fma_f32 %3, %11, %9, %3" W6_SEL3_LO "\n\t"                           \
+                         "v_pk_add_f32 %0, %2, %3\n\t"                                              \
+                         "v_pk_add_f32 %1, %2, %3 neg_lo:[0,1] neg_hi:[0,1]"                        \
+                         : "=&v"(V[vp_][5]), "=&v"(V[vp_][6]), "=&v"(P__), "=&v"(Q__)               \
+                         : "v"(R[2]), "v"(R[4]), "v"(R[6]), "v"(R[1]), "v"(R[3]), "v"(R[5]), "s"(qE), "s"(qC), "s"(qD)); \
         }                                                                                           \
     } while (0)
 
@@ -483,6 +512,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         }                                                                                           \
         _Pragma("unroll") for (int b = 0; b < 8; ++b)                                               \
             _Pragma("unroll") for (int mt = 0; mt < NT; ++mt) acc[b][mt] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        /* the bias rides in the accumulators: A^T's column of the point x = 1 is all ones, so a constant added to M[xi = (1, 1)] comes out */ \
+        /* of A^T M A as that constant in every output pixel -- wave 1 starts its b = 1 accumulators at the bias instead of zero */ \
+        {                                                                                           \
+            int z__ = 0;                                                                            \
+            asm volatile("" : "+v"(z__));                                                           \
+            const int q4__ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z__)) >> 4; \
+            const float bsel__ = wave == 1 ? 1.f : 0.f;                                             \
+            _Pragma("unroll") for (int mt = 0; mt < NT; ++mt)                                       \
+                acc[1][mt] = *reinterpret_cast<const f32x4 *>(smem + BIAS_OFF + ((cur_nb - p.nb0) * 64 + 16 * mt + 4 * q4__) * 4) * bsel__; \
+        }                                                                                           \
     } while (0)
     // bookkeeping around a period: the chunk that follows the compute side's (the next item's first after the last), then the period, then --
     // after an item's last chunk -- the output stage and the step to the block's next item

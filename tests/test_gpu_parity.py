@@ -1168,3 +1168,72 @@ def test_conv3x3_wino_eight_wave_form_bit_identical(hard, B, ci, co, h, w):
     np.testing.assert_array_equal(a4, a8)
     np.testing.assert_array_equal(a4, a8n)
     np.testing.assert_allclose(a8, O.conv3x3(x, wt, b, 1, True), rtol=2e-5, atol=1e-4)      # F(2x2) rounding on up to 562 input channels
+
+
+@pytest.mark.parametrize("ci,co,h,w,blocks", [(128, 128, 40, 70, 3), (200, 128, 33, 65, 5), (32, 64, 17, 100, 2), (104, 192, 48, 33, 7), (64, 100, 70, 31, 64),
+                                              (40, 160, 16, 32, 2), (32, 32, 49, 35, 5), (128, 96, 36, 83, 17), (64, 32, 20, 70, 3), (232, 128, 12, 48, 1),
+                                              (264, 128, 6, 6, 1), (72, 36, 25, 49, 4)])
+def test_conv3x3_wino6(hard, ci, co, h, w, blocks):
+    """Winograd F(6x6,3x3) (csrc/b2f_wino6.hip, option wino6 -- the default kernel of the wide stride-1 layers on maps of at least
+    wino6_min_pixels pixels), forced at test sizes: blocks of 64 outputs and the 32-output block of layers whose outputs are <= 32 mod 64,
+    odd and even chunk counts, ragged edges, one to many items per persistent block.  Against the oracle at the bars of the F(4x4)
+    kernel (tools/wino6_numerics.py: its fp32 rounding is 1.3 - 2.8 x F(4x4)'s and inside them), against an fp64 convolution within
+    3 x the F(4x4) kernel's own error, and bit for bit against itself with another number of blocks (batching must not change a bit)."""
+    import torch
+    r = _rng(ci * 13 + co + blocks)
+    x = r.standard_normal((3, ci, h, w), dtype=np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    b = r.standard_normal(co, dtype=np.float32)
+    with hard.options(wino6=0):
+        f4 = ops.conv3x3(hard, x, wt, b, 1, True)
+    with hard.options(wino6=1, wino6_min_pixels=0):
+        with hard.options(wino4_persistent=blocks):          # values > 1: exactly that many persistent blocks
+            got = ops.conv3x3(hard, x, wt, b, 1, True)
+        full = ops.conv3x3(hard, x, wt, b, 1, True)
+    exp = O.conv3x3(x, wt, b, 1, True)
+    np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1.5e-4)
+    assert np.abs(got - exp).mean() < 5e-6
+    assert np.array_equal(got, full)
+    assert not np.array_equal(got, f4)                       # the other kernel really ran
+    y = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
+    e64 = torch.where(y > 0, y, 0.2 * y).numpy()
+    assert np.abs(got - e64).max() <= 3.0 * np.abs(f4 - e64).max() + 1e-5
+
+
+@pytest.mark.parametrize("scale", [1e-3, 30.0, 1e3])
+@pytest.mark.parametrize("ci,co,h,w", [(128, 128, 33, 65), (200, 96, 40, 70)])
+def test_conv3x3_wino6_activation_scale(hard, scale, ci, co, h, w):
+    """The F(6x6) transforms (coefficients up to 32 in A^T, 21/4 in B^T) amplify fp32 rounding RELATIVE to the activations: the error bars must
+    hold in proportion at any activation scale (the bias rides in the accumulators: scaled with the activations here, and not at all below)."""
+    r = _rng(int(ci + co + scale) + 1)
+    x = (r.standard_normal((2, ci, h, w), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    wt = (r.standard_normal((co, ci, 3, 3), dtype=np.float32) / np.sqrt(9 * ci)).astype(np.float32)
+    for bscale in (scale, 1.0):
+        b = (r.standard_normal(co, dtype=np.float32) * np.float32(bscale)).astype(np.float32)
+        with hard.options(wino6=1, wino6_min_pixels=0):
+            got = ops.conv3x3(hard, x, wt, b, 1, False)
+        exp = O.conv3x3(x, wt, b, 1, False)
+        np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1.5e-4 * max(scale, bscale))
+        assert np.abs(got - exp).mean() < 5e-6 * max(scale, bscale)
+
+
+def test_compute_flow_with_the_f6x6_kernel(hard):
+    """The whole graph with every F(4x4)-class layer on the F(6x6) kernel (wino6_min_pixels = 0 and wino4_min_pixels = 0 send every eligible layer
+    there at this size): the end-to-end bar of the contract, and 1e-5 of the F(4x4) path on the flow (another kernel, the same function)."""
+    r = _rng(16)
+    H, Wd = 128, 256
+    ims = _triplet(r, H, Wd)
+    eflow, efo, ebo, fnet, onet = O.compute_flow(*ims, W.random_init(5, False, 2.0), False, want_net=True)
+    with hard.options(wino4_min_pixels=0, adaptive_kernels=0, host_graph=0):
+        with hard.options(wino6=0):
+            base, _, _ = hard.computeFlow(*ims)
+        with hard.options(wino6=1, wino6_min_pixels=0):
+            flow, fo, bo = hard.computeFlow(*ims)
+        with hard.options(wino6=0):
+            again, _, _ = hard.computeFlow(*ims)
+    d = np.abs(flow - eflow)
+    assert np.abs(eflow).max() > 0.02 and d.max() <= 1e-3, d.max()
+    assert not np.array_equal(flow, base) and np.abs(flow - base).max() < 1e-5
+    assert np.array_equal(again, base)
+    near = np.abs(onet - 0.6666) < 1e-3
+    assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
