@@ -73,6 +73,19 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 #ifndef W6_ABLATE
 #define W6_ABLATE 0
 #endif
+// cache policy bits of the raw-patch loads / the output stores / the weight loads (buffer instruction aux: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef W6_RAW_AUX
+#define W6_RAW_AUX 0
+#endif
+#ifndef W6_OUT_AUX
+#define W6_OUT_AUX 0
+#endif
+#ifndef W6_B_AUX
+#define W6_B_AUX 0
+#endif
+#ifndef W6_NB_XCD
+#define W6_NB_XCD 0
+#endif
 #ifndef W6_RING
 #define W6_RING 8      // slots of the weight ring (power of two): loads run W6_RING - 1 steps ahead
 #endif
@@ -196,7 +209,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
                 // emits no wait state before a VALU write of the store's data registers -- LLVM's hazard rule exempts that form -- and on gfx950
                 // the next instruction's result reached memory in some lanes: first output of a quad wrong, run to run different)
                 const unsigned vo = (ok && oy + 2 * i < p.Ho) ? ooff + (unsigned)(i * rowstep) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), o_rsrc, (int)vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), o_rsrc, (int)vo, 0, W6_OUT_AUX);
             }
             __builtin_amdgcn_sched_barrier(0);                                  // one round at a time: hoisting the next round's reads spilled registers
         }
@@ -268,11 +281,23 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     int nxt_nb, nxt_img, nxt_ox0, nxt_oy0;
     bool has_next;
     int lc = 0;                                                              // load side: next chunk of its item
+    // Virtual block index -> item.  Default: every XCD walks a contiguous range of (tile, n-block) with the n-block fastest (the n-blocks of a
+    // tile run side by side and share the raw patch in L2).  W6_NB_XCD (launches of 2, 4 or 8 n-blocks whose tile count divides evenly): an XCD
+    // works on ONE n-block -- its L2 then holds that n-block's weights only (200 -> 128: 3.2 of 6.4 MB; an L2 has 4 MB) -- and a contiguous
+    // range of tiles; the patch is read by nblk XCDs instead of one.
+    const int nb_xcd = (W6_NB_XCD && p.nblk > 1 && 8 % p.nblk == 0 && (G & 7) == 0 && (total / p.nblk) % (8 / p.nblk) == 0) ? 1 : 0;
 #define W6_DECODE(v_, nb_, img_, ox0_, oy0_)                                                        \
     do {                                                                                            \
-        int bid__ = xcd_remap((v_), total);                                                         \
-        nb_ = bid__ % p.nblk + p.nb0;                                                               \
-        bid__ /= p.nblk;                                                                            \
+        int bid__;                                                                                  \
+        if (nb_xcd) {                                                                               \
+            const int xcd__ = (v_) & 7, k__ = (v_) >> 3;                                            \
+            nb_ = xcd__ % p.nblk + p.nb0;                                                           \
+            bid__ = (xcd__ / p.nblk) * ((total / p.nblk) / (8 / p.nblk)) + k__;                     \
+        } else {                                                                                    \
+            bid__ = xcd_remap((v_), total);                                                         \
+            nb_ = bid__ % p.nblk + p.nb0;                                                           \
+            bid__ /= p.nblk;                                                                        \
+        }                                                                                           \
         ox0_ = (bid__ % tiles_x) * OW;                                                              \
         bid__ /= tiles_x;                                                                           \
         oy0_ = (bid__ % tiles_y) * OH;                                                              \
@@ -308,7 +333,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
             unsigned vo__;                                                                          \
             asm("v_cndmask_b32_e64 %0, -16, %1, %2" : "=v"(vo__) : "v"(l_off), "s"(mk[i]));         \
-            sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs__, (int)vo__, so__ + (i == 2 ? 9 : 5 * i) * rowbytes, 0)); \
+            sr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs__, (int)vo__, so__ + (i == 2 ? 9 : 5 * i) * rowbytes, W6_RAW_AUX)); \
         }                                                                                           \
         const bool wrap__ = lc + 1 == nchunks, sw__ = wrap__ && has_next;                           \
         lc = wrap__ ? (has_next ? 0 : nchunks - 1) : lc + 1;                                        \
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
 #define W6_B_LOAD(u_)                                                                               \
     do {                                                                                            \
         const int o__ = (u_) < NSTEP ? bo_c + (u_) * 1024 : bo_n + ((u_) - NSTEP) * 1024;           \
-        bq[(u_) & (W6_RING - 1)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_voff, o__, 0)); \
+        bq[(u_) & (W6_RING - 1)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)b_voff, o__, W6_B_AUX)); \
     } while (0)
     // MFMA i of step st_: (b, K step s, output tile mt) = (st >> 1, st & 1, i) resp. (st, i >> 1, i & 1)
 #define W6_MFMA(pp_, st_, i_)                                                                       \

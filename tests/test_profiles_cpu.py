@@ -23,7 +23,7 @@ def test_traffic_profile_is_not_older_than_the_kernels_it_describes():
     t_prof = _git("log", "-1", "--format=%ct", "--", newest).stdout.strip()
     assert t_prof, "%s is not committed" % newest
     # the kernels of the default bench path whose HBM traffic the file reports (conv class + warp_costvol)
-    kernels = ["back2future_amd/csrc/" + f for f in ("b2f_wino4.hip", "b2f_wino.hip", "b2f_conv.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_s2b.hip", "b2f_w1b.hip", "b2f_corr.hip",
+    kernels = ["back2future_amd/csrc/" + f for f in ("b2f_wino6.hip", "b2f_wino4.hip", "b2f_wino.hip", "b2f_conv.hip", "b2f_conv16.hip", "b2f_head.hip", "b2f_convb.hip", "b2f_s2b.hip", "b2f_w1b.hip", "b2f_corr.hip",
                                                      "b2f_corr5.hip", "b2f_corr5_loop.inc", "b2f_glue.hip")]
     t_k = _git("log", "-1", "--format=%ct", "--", *kernels).stdout.strip()
     assert int(t_prof) >= int(t_k), ("%s was committed before the last change to the kernels it describes: re-run "

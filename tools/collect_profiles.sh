@@ -4,7 +4,7 @@
 #   bash tools/collect_profiles.sh r01    ->  gpurun_out/profiles_r01/...  (copy the summaries into profiles/)
 set -u
 TAG=${1:-r01}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

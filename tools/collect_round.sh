@@ -2,7 +2,7 @@
 # Everything the round's evidence needs, at the current HEAD, in one GPU call:
 #   bash tools/collect_round.sh r04   ->  gpurun_out/profiles_r04/*, gpurun_out/sq_r04/*  (copy the summaries into profiles/)
 TAG=${1:-r04}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
 cd $R
 mkdir -p gpurun_out/profiles_$TAG
 python3 bench.py > gpurun_out/profiles_$TAG/${TAG}_bench_default.json 2> gpurun_out/profiles_$TAG/bench_default.err
