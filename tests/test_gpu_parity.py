@@ -1237,3 +1237,31 @@ def test_compute_flow_with_the_f6x6_kernel(hard):
     assert np.array_equal(again, base)
     near = np.abs(onet - 0.6666) < 1e-3
     assert ((fo != efo) & ~near[1:2]).sum() == 0 and ((bo != ebo) & ~near[0:1]).sum() == 0
+
+
+def test_multi_gpu_eight_replicas_partition_of_config4(monkeypatch):
+    """BASELINE.json configs[4]'s partition on the one-GPU box: EIGHT replicas (B2F_MULTI_ALLOW_DUPLICATE lists GPU 0 eight times: eight contexts,
+    eight worker threads, the peer broadcast from replica 0), n = 128 byte triplets -> 16 per replica, and an uneven n = 100 -> 13, 13, 13, 13,
+    12, 12, 12, 12 (the contiguous dim-1 split of nn.DataParallelTable, util.lua:27-48), through b2f_multi_compute_flow_batch_u8 straight into
+    the caller's buffers: bit-identical to one context.  (Small frames: the partition is what is tested, not the throughput.)"""
+    monkeypatch.setenv("B2F_MULTI_TRANSPORT", "peer")
+    monkeypatch.setenv("B2F_MULTI_ALLOW_DUPLICATE", "1")
+    r = _rng(29)
+    H0, W0 = 64, 128
+    by = [r.integers(0, 256, (128, 3, H0, W0), dtype=np.uint8) for _ in range(3)]
+    mm = back2future.MultiModel("random:hard:3:2.0", n_gpus=8, devices=[0] * 8)
+    ref = back2future.Model("random:hard:3:2.0")
+    try:
+        assert mm.n_gpus == 8 and len(set(mm.weights_checksums())) == 1
+        assert [back2future.shard_range(128, i, 8) for i in range(8)] == [(16 * i, 16 * i + 16) for i in range(8)]
+        sizes = [back2future.shard_range(100, i, 8)[1] - back2future.shard_range(100, i, 8)[0] for i in range(8)]
+        assert sizes == [13, 13, 13, 13, 12, 12, 12, 12]
+        exp = ref.computeFlowBatch(*by)
+        for a, b in zip(mm.computeFlowBatch(*by), exp):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(mm.computeFlowBatch(*[x[:100] for x in by]), [e[:100] for e in exp]):
+            np.testing.assert_array_equal(a, b)
+        assert float(np.abs(exp[0]).max()) > 0.01
+    finally:
+        mm.close()
+        ref.close()
