@@ -45,10 +45,11 @@ def test_samples_triplet_with_weights_like_trained(variant):
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "samples")
     ims = [flow_io.load_image(os.path.join(d, "frame_%04d.png" % i)) for i in (9, 10, 11)]
     x = np.concatenate(ims, 0)[None]
-    xs = np.stack([O.image_scale_bilinear(pl, 320, 1216) for pl in ((x[0] + (-MEAN[0])) / STD[0]).astype(np.float32)])[None]
-    params = TL.calibrate(W.random_init(7, True, 1.0), xs, True)
+    xs = O.image_scale_bilinear(((x[0] + (-MEAN[0])) / STD[0]).astype(np.float32), 320, 1216)[None]
+    params = W.random_init(7, True, 1.0)
     if variant == "outlier-filters":
-        params = TL.add_outliers(params, True)
+        params = TL.add_outliers(params, True)        # first the outliers, then the scale: every layer's output has unit deviation, 3 % of its channels 10 x the rest
+    params = TL.calibrate(params, xs, True)
     _check("samples 320x1216 soft " + variant, ims, params, True)
 
 
@@ -60,7 +61,8 @@ def test_full_hd_triplet_with_weights_like_trained(variant):
     x = bench.make_triplets(torch, 1, 1024, 1920, seed=3, device=torch.device("cuda", 0)).cpu().numpy()
     ims = [np.ascontiguousarray(x[0, 3 * f:3 * f + 3]) for f in range(3)]
     xn = ((x + (-MEAN)) / STD).astype(np.float32)
-    params = TL.calibrate(W.random_init(9, False, 1.0), xn, False)
+    params = W.random_init(9, False, 1.0)
     if variant == "outlier-filters":
         params = TL.add_outliers(params, False)
+    params = TL.calibrate(params, xn, False)
     _check("1024x1920 hard " + variant, ims, params, False)

@@ -3,8 +3,9 @@
 A random-init model's activations shrink layer by layer (Torch's reset() scale with LeakyReLU(0.2) loses a factor ~6 of variance per conv),
 so the decoders of a random model work on tiny numbers and every kernel's rounding looks harmless.  `calibrate` rescales every convolution
 of the pruned computeFlow graph (weights and bias) so that its output has unit standard deviation on a given input -- what batch statistics
-of a trained network look like --, `add_outliers` then multiplies a few output filters per layer by 10 (heavy-tailed channels, the case
-Winograd transforms like least).  Test infrastructure: the PyTorch-CPU statement of the graph (oracle/torch_cpu.py) does the walking."""
+of a trained network look like.  `add_outliers`, applied BEFORE it, multiplies a few output filters per layer by 10: after the calibration
+every layer still has unit deviation overall, carried by 3 % of its channels at 10 x the rest (heavy-tailed channels, the case Winograd
+transforms like least).  Test infrastructure: the PyTorch-CPU statement of the graph (oracle/torch_cpu.py) does the walking."""
 import numpy as np
 
 
