@@ -83,6 +83,9 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 #ifndef W6_B_AUX
 #define W6_B_AUX 0
 #endif
+#ifndef W6_NB_DELAY
+#define W6_NB_DELAY 0
+#endif
 #ifndef W6_NB_XCD
 #define W6_NB_XCD 0
 #endif
@@ -496,6 +499,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     // ---- first item: prologue ----
     int v_cur = blockIdx.x;
     W6_DECODE(v_cur, cur_nb, cur_img, cur_ox0, cur_oy0);
+    // The n-blocks of a tile run on neighbouring CUs of one XCD and read the same raw patch.  Started together they miss L2 together; the odd
+    // n-blocks start W6_NB_DELAY x 64 cycles late (about a chunk period) and keep that distance -- every item takes the same time --, so their
+    // patch loads find the lines the even n-block fetched a period earlier (weight loads queue behind the patch loads: vmcnt is in order).
+    if (W6_NB_DELAY > 0 && p.nblk > 1 && ((cur_nb - p.nb0) & 1)) __builtin_amdgcn_s_sleep(W6_NB_DELAY);
     W6_MASKS(cur_ox0, cur_oy0, mk);
     W6_BASES(cur_img, cur_ox0, cur_oy0, ld_b0, ld_b1);
     nxt_b0 = ld_b0; nxt_b1 = ld_b1;
