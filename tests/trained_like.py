@@ -9,8 +9,10 @@ transforms like least).  Test infrastructure: the PyTorch-CPU statement of the g
 import numpy as np
 
 
-def calibrate(params, x, past_flow, target=1.0):
-    """params: canonical flat weights; x: B x 9 x H x W normalized input.  Returns a rescaled copy."""
+def calibrate(params, x, past_flow, target=1.0, target_flow=0.25):
+    """params: canonical flat weights; x: B x 9 x H x W normalized input.  Returns a rescaled copy.  The 2-output heads (flow / 20, occlusion
+    logits) get deviation `target_flow`: flows of a few units = tens of pixels at full resolution, as in KITTI; at deviation 1 the warps
+    amplify ANY fp32 difference (the oracle's own included) to the contract's 1e-3 and the comparison measures that, not the kernels."""
     import torch
     import torch.nn.functional as F
     from oracle import torch_cpu as T
@@ -24,8 +26,9 @@ def calibrate(params, x, past_flow, target=1.0):
             seen.add(key)
             s = float(F.conv2d(xx, wb[0], wb[1], stride=stride, padding=1).std())
             if s > 0:
-                wb[0].mul_(target / s)
-                wb[1].mul_(target / s)
+                t = target_flow if wb[0].shape[0] == 2 else target
+                wb[0].mul_(t / s)
+                wb[1].mul_(t / s)
         return orig(xx, wb, stride, leaky)
     T._conv = conv
     try:
