@@ -89,6 +89,16 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 #ifndef W6_NB_XCD
 #define W6_NB_XCD 0
 #endif
+// Profiling only: -DW6_TRACE=1 + B2F_WINO_TRACE=<chunks of the layer> in the environment: s_memtime stamps of block 40 (waves 0 and 4) around the
+// K loop and inside the output stage of its first items, printed by the launcher
+#ifndef W6_TRACE
+#define W6_TRACE 0
+#endif
+#if W6_TRACE
+#define W6_T(k_) do { tr_buf[(tr_item < 6 ? tr_item : 6) * 16 + (k_)] = clock64(); } while (0)   /* no branch: every wave stores, all but two into a dummy area */
+#else
+#define W6_T(k_) do {} while (0)
+#endif
 #ifndef W6_RING
 #define W6_RING 8      // slots of the weight ring (power of two): loads run W6_RING - 1 steps ahead
 #endif
@@ -126,7 +136,7 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 //   * Stores are buffer stores whose offset is -16 for anything outside the tensor (dropped by the range check): no control flow.
 template <int NT>
 __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *smem, const ConvLaunch &p, int tid, int lane, int wave, int nb,
-                                             int img, int ox0, int oy0)
+                                             int img, int ox0, int oy0, bool tr_on, int tr_item, long long *tr_buf)
 {
     using namespace wino6;
     // the lane id through an opaque register: everything derived from it is computed HERE and not hoisted out of the K loop (hoisted, it sat
@@ -141,6 +151,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
     const int t16 = lane & 15, q4 = lane >> 4;
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * p.out_img_stride, 0, 0x7fffffff, 0x00020000);
     const float slope = p.leaky ? 0.2f : 1.f;
+    const f32x2 pSl = {slope, slope};
     const int rowstep = 2 * p.Wo * p.out_pix_stride * 4;                     // bytes between the rows an item stores
 #pragma unroll
     for (int ps = 0; ps < NT / 2; ++ps) {
@@ -154,20 +165,42 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
             for (int hf = 0; hf < 2; ++hf) {
                 f32x2 m0 = W6_HALF(acc[0][mt], hf), m1 = W6_HALF(acc[1][mt], hf), m2 = W6_HALF(acc[2][mt], hf), m3 = W6_HALF(acc[3][mt], hf);
                 f32x2 m4 = W6_HALF(acc[4][mt], hf), m5 = W6_HALF(acc[5][mt], hf), m6 = W6_HALF(acc[6][mt], hf), m7 = W6_HALF(acc[7][mt], hf);
-                f32x2 s1, d1, s2, d2, s3, d3, t1, t2, t3, t4;
-                W6_PK_ADD(s1, m1, m2); W6_PK_SUB(d1, m1, m2); W6_PK_ADD(s2, m3, m4); W6_PK_SUB(d2, m3, m4); W6_PK_ADD(s3, m5, m6); W6_PK_SUB(d3, m5, m6);
-                W6_PK_ACC(m0, s1); W6_PK_ACC(m0, s2); W6_PK_ACC(m0, s3);                               // T0 = M0 + s1 + s2 + s3
-                W6_PK_FMA(t1, c2h, LO, d2, d1); W6_PK_FMA_ACC(t1, c2h, HI, d3);                        // T1 = d1 + 2 d2 + d3/2
-                W6_PK_FMA(t2, c4h, LO, s2, s1); W6_PK_FMA_ACC(t2, c4h, HI, s3);                        // T2 = s1 + 4 s2 + s3/4
-                W6_PK_FMA(t3, c8h, LO, d2, d1); W6_PK_FMA_ACC(t3, c8h, HI, d3);                        // T3 = d1 + 8 d2 + d3/8
-                W6_PK_FMA(t4, c16h, LO, s2, s1); W6_PK_FMA_ACC(t4, c16h, HI, s3);                      // T4 = s1 + 16 s2 + s3/16
-                W6_PK_FMA_ACC(d1, c32h, LO, d2); W6_PK_FMA_ACC(d1, c32h, HI, d3); W6_PK_ACC(m7, d1);   // T5 = d1 + 32 d2 + d3/32 + M7
+                // T0 = M0 + s1 + s2 + s3, T1 = d1 + 2 d2 + d3/2, T2 = s1 + 4 s2 + s3/4, T3 = d1 + 8 d2 + d3/8, T4 = s1 + 16 s2 + s3/16,
+                // T5 = d1 + 32 d2 + d3/32 + M7  with s = M1+M2, M3+M4, M5+M6 and d the differences -- one asm statement (no padding between its ops)
+                // In place: s1, s2, s3 in three temporaries, d1, d2, d3 over M2, M4, M6, then T1 -> M1, T3 -> M3, T2 -> M5, T4 -> s1's register, T0 -> M0,
+                // T5 -> M7 (the statement holds 11 register pairs; with separate outputs it held 20 and the kernel spilled).
+                f32x2 s1, s2, s3;
+                asm volatile("v_pk_add_f32 %0, %4, %5\n\t"                                     /* s1 = M1 + M2 */
+                             "v_pk_add_f32 %5, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"           /* d1 = M1 - M2  (over M2) */
+                             "v_pk_add_f32 %1, %6, %7\n\t"                                     /* s2 */
+                             "v_pk_add_f32 %7, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"           /* d2 (over M4) */
+                             "v_pk_add_f32 %2, %8, %9\n\t"                                     /* s3 */
+                             "v_pk_add_f32 %9, %8, %9 neg_lo:[0,1] neg_hi:[0,1]\n\t"           /* d3 (over M6) */
+                             "v_pk_add_f32 %3, %3, %0\n\t"                                     /* T0 = M0 + s1 + s2 + s3 */
+                             "v_pk_fma_f32 %4, %11, %7, %5" W6_SEL3_LO "\n\t"                  /* T1 = d1 + 2 d2 ... (over M1) */
+                             "v_pk_fma_f32 %8, %12, %1, %0" W6_SEL3_LO "\n\t"                  /* T2 = s1 + 4 s2 ... (over M5) */
+                             "v_pk_fma_f32 %6, %13, %7, %5" W6_SEL3_LO "\n\t"                  /* T3 = d1 + 8 d2 ... (over M3) */
+                             "v_pk_add_f32 %3, %3, %1\n\t"
+                             "v_pk_fma_f32 %4, %11, %9, %4" W6_SEL3_HI "\n\t"                  /* ... + d3/2 */
+                             "v_pk_fma_f32 %8, %12, %2, %8" W6_SEL3_HI "\n\t"                  /* ... + s3/4 */
+                             "v_pk_fma_f32 %6, %13, %9, %6" W6_SEL3_HI "\n\t"                  /* ... + d3/8 */
+                             "v_pk_add_f32 %3, %3, %2\n\t"
+                             "v_pk_fma_f32 %0, %14, %1, %0" W6_SEL3_LO "\n\t"                  /* T4 = s1 + 16 s2 ... (over s1) */
+                             "v_pk_fma_f32 %5, %15, %7, %5" W6_SEL3_LO "\n\t"                  /* d1 + 32 d2 ... (over d1) */
+                             "v_pk_fma_f32 %0, %14, %2, %0" W6_SEL3_HI "\n\t"                  /* ... + s3/16 */
+                             "v_pk_fma_f32 %5, %15, %9, %5" W6_SEL3_HI "\n\t"                  /* ... + d3/32 */
+                             "v_pk_add_f32 %10, %10, %5"                                       /* T5 = ... + M7 */
+                             : "=&v"(s1), "=&v"(s2), "=&v"(s3), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "+v"(m6), "+v"(m7)
+                             : "s"(c2h), "s"(c4h), "s"(c8h), "s"(c16h), "s"(c32h));
+                const f32x2 t1 = m1, t2 = m5, t3 = m3, t4 = s1;
                 f32x2 *d2p = reinterpret_cast<f32x2 *>(dp + 8 * hf);
                 d2p[0 * (XPS / 8)] = m0; d2p[1 * (XPS / 8)] = t1; d2p[2 * (XPS / 8)] = t2;
                 d2p[3 * (XPS / 8)] = t3; d2p[4 * (XPS / 8)] = t4; d2p[5 * (XPS / 8)] = m7;
             }
         }
+        W6_T(2 + 3 * ps);
         W6_LDS_BARRIER();
+        W6_T(3 + 3 * ps);
         // parity is wave-uniform (waves 0-3 even rows, 4-7 odd rows): its coefficients are scalars, two per SGPR pair, and the arithmetic is the
         // packed asm of the K loop (as elementwise vector code hipcc kept every splat coefficient in a VGPR pair: 20 registers, spilled)
         const int par = wave >> 2;
@@ -190,24 +223,40 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const f32x2 *xh = reinterpret_cast<const f32x2 *>(xb + 8 * hf);
-                const f32x2 m1 = xh[1 * 6 * (XPS / 8)], m2 = xh[2 * 6 * (XPS / 8)], m3 = xh[3 * 6 * (XPS / 8)], m4 = xh[4 * 6 * (XPS / 8)];
-                const f32x2 m5 = xh[5 * 6 * (XPS / 8)], m6 = xh[6 * 6 * (XPS / 8)], me = *reinterpret_cast<const f32x2 *>(xb + 8 * hf + xe_off);
-                f32x2 e1, e2, e3;
-                W6_PK_FMA(e1, pSK, LO, m2, m1);
-                W6_PK_FMA(e2, pSK, LO, m4, m3);
-                W6_PK_FMA(e3, pSK, LO, m6, m5);
-                W6_PK_FMA(y[0][hf], pSK, HI, me, e1); W6_PK_FMA_ACC(y[0][hf], pA, LO, e2); W6_PK_FMA_ACC(y[0][hf], pA, HI, e3);
-                W6_PK_FMA(y[1][hf], pB, LO, e2, e1); W6_PK_FMA_ACC(y[1][hf], pB, HI, e3);
-                W6_PK_FMA(y[2][hf], pC, LO, e2, e1); W6_PK_FMA_ACC(y[2][hf], pC, HI, e3); W6_PK_FMA_ACC(y[2][hf], pK7, LO, me);
+                f32x2 m1 = xh[1 * 6 * (XPS / 8)], m2 = xh[2 * 6 * (XPS / 8)], m3 = xh[3 * 6 * (XPS / 8)], m4 = xh[4 * 6 * (XPS / 8)];
+                f32x2 m5 = xh[5 * 6 * (XPS / 8)], m6 = xh[6 * 6 * (XPS / 8)];
+                const f32x2 me = *reinterpret_cast<const f32x2 *>(xb + 8 * hf + xe_off);
+                // in place: e1, e2, e3 over M1, M3, M5; the three rows over M2, M4, M6
+                asm volatile("v_pk_fma_f32 %0, %7, %1, %0" W6_SEL3_LO "\n\t"                   /* e1 = M1 +- M2 */
+                             "v_pk_fma_f32 %2, %7, %3, %2" W6_SEL3_LO "\n\t"                   /* e2 = M3 +- M4 */
+                             "v_pk_fma_f32 %4, %7, %5, %4" W6_SEL3_LO "\n\t"                   /* e3 = M5 +- M6 */
+                             "v_pk_fma_f32 %1, %7, %6, %0" W6_SEL3_HI "\n\t"                   /* row A = k0 Me + e1 ... */
+                             "v_pk_fma_f32 %3, %9, %2, %0" W6_SEL3_LO "\n\t"                   /* row B = e1 + b2 e2 ... */
+                             "v_pk_fma_f32 %5, %10, %2, %0" W6_SEL3_LO "\n\t"                  /* row C = e1 + c2 e2 ... */
+                             "v_pk_fma_f32 %1, %8, %2, %1" W6_SEL3_LO "\n\t"                   /* ... + a2 e2 */
+                             "v_pk_fma_f32 %3, %9, %4, %3" W6_SEL3_HI "\n\t"                   /* ... + b3 e3 */
+                             "v_pk_fma_f32 %5, %10, %4, %5" W6_SEL3_HI "\n\t"                  /* ... + c3 e3 */
+                             "v_pk_fma_f32 %1, %8, %4, %1" W6_SEL3_HI "\n\t"                   /* ... + a3 e3 */
+                             "v_pk_fma_f32 %5, %11, %6, %5" W6_SEL3_LO                         /* ... + k7 Me */
+                             : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "+v"(m6)
+                             : "v"(me), "s"(pSK), "s"(pA), "s"(pB), "s"(pC), "s"(pK7));
+                y[0][hf] = m2; y[1][hf] = m4; y[2][hf] = m6;
             }
             const int oy = oy0 + 6 * tyy + par, ox = ox0 + x;
             const unsigned ooff = (unsigned)(((size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co0 & 7)) * 4);
             const bool ok = co0 < p.cout && ox < p.Wo;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                f32x4 v = __builtin_shufflevector(y[i][0], y[i][1], 0, 1, 2, 3);               // (the bias came through the accumulators: W6_ITEM_START)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaxf(v[k], slope * v[k]);   // LeakyReLU(0.2): v > 0 ? v : 0.2 v  (slope 1: identity)
+                // LeakyReLU(0.2) = max(v, 0.2 v) (slope 1: identity): two packed multiplies, four plain maxima as asm (fmaxf() costs a second
+                // v_max per element: hipcc canonicalises NaNs first).  The bias came through the accumulators (W6_ITEM_START).
+                f32x2 tl0, tl1;
+                W6_PK_MUL(tl0, pSl, LO, y[i][0]);
+                W6_PK_MUL(tl1, pSl, LO, y[i][1]);
+                f32x4 v;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[0]) : "v"(y[i][0][0]), "v"(tl0[0]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[1]) : "v"(y[i][0][1]), "v"(tl0[1]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[2]) : "v"(y[i][1][0]), "v"(tl1[0]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[3]) : "v"(y[i][1][1]), "v"(tl1[1]));
                 // (the row offset goes into the lane offset, NOT into the scalar offset: behind a 16-byte buffer store with a register soffset hipcc
                 // emits no wait state before a VALU write of the store's data registers -- LLVM's hazard rule exempts that form -- and on gfx950
                 // the next instruction's result reached memory in some lanes: first output of a quad wrong, run to run different)
@@ -216,6 +265,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
             }
             __builtin_amdgcn_sched_barrier(0);                                  // one round at a time: hoisting the next round's reads spilled registers
         }
+        W6_T(4 + 3 * ps);
     }
 }
 
@@ -532,6 +582,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
     for (int part = 0; part < 4; ++part) W6_COLPASS(part, 0);
     W6_LDS_BARRIER();                                                        // slot 0 is read: period 0 overwrites it
 
+    const bool tr_on = W6_TRACE && p.trace && p.nb0 >= 0 && blockIdx.x == 40 && (wave == 0 || wave == 4) && p.w8 == 77;
+    long long *tr_buf = W6_TRACE ? (p.trace ? p.trace : reinterpret_cast<long long *>(p.out)) + (tr_on ? (wave >> 2) * 128 : 256) : nullptr;
+    int tr_item = 0;
     int c = 0;                                                               // compute side: chunk of the current item
     bool more = true;
 #define W6_ITEM_START()                                                                             \
@@ -563,17 +616,22 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         W6_PERIOD(PP_);                                                                             \
         bo_c = bo_n;                                                                                \
         if (++c == nchunks) {                                                                       \
-            wino6_output<NT>(acc, smem, p, tid, lane, wave, cur_nb, cur_img, cur_ox0, cur_oy0);     \
+            W6_T(1);                                                                                \
+            wino6_output<NT>(acc, smem, p, tid, lane, wave, cur_nb, cur_img, cur_ox0, cur_oy0, tr_on, tr_item, tr_buf); \
             if (!has_next) { more = false; }                                                        \
             else {                                                                                  \
                 v_cur += G;                                                                         \
                 cur_nb = nxt_nb; cur_img = nxt_img; cur_ox0 = nxt_ox0; cur_oy0 = nxt_oy0;           \
                 c = 0;                                                                              \
                 W6_ITEM_START();                                                                    \
+                W6_T(8);                                                                            \
+                ++tr_item;                                                                          \
+                W6_T(0);                                                                            \
             }                                                                                       \
         }                                                                                           \
     } while (0)
     W6_ITEM_START();
+    W6_T(0);
     while (more) {
         W6_RUN(0);
         if (!more) break;
@@ -634,10 +692,41 @@ static hipError_t launch_wino6_t(const ConvLaunch &p, int nb0, int nblk, hipStre
     q.nb0 = nb0;
     q.nblk = nblk;
     q.trace = nullptr;
+#if W6_TRACE
+    static long long *trace_dev = nullptr;
+    static int traced = 0;
+    const int tr_want = getenv("B2F_WINO_TRACE") ? atoi(getenv("B2F_WINO_TRACE")) : 0;
+    const int nch = p.seg[0].nchunks + (p.nseg > 1 ? p.seg[1].nchunks : 0);
+    const bool do_trace = NT == 4 && tr_want == nch && traced < 1 && p.H * p.W >= 256 * 480;
+    if (do_trace) {
+        if (!trace_dev) hipMalloc(&trace_dev, 512 * sizeof(long long));
+        hipMemsetAsync(trace_dev, 0, 512 * sizeof(long long), s);
+    }
+    if (!trace_dev) hipMalloc(&trace_dev, 512 * sizeof(long long));
+    q.trace = trace_dev;                 // (every launch of a trace build stamps: untraced ones into the dummy area)
+    q.w8 = do_trace ? 77 : 0;            // (the kernel does not read w8: marks the traced launch)
+#endif
     const long items = (long)((p.Wo + OW - 1) / OW) * ((p.Ho + OH - 1) / OH) * p.nimg * nblk;
     const int pcap = p.w4_persist > 1 ? p.w4_persist : n_cu;               // (tests: exactly that many blocks)
     const int grid = (int)(items < pcap ? items : pcap);
     hipLaunchKernelGGL((conv3x3_wino6<NT>), dim3((unsigned)grid), dim3(512), LDS_BYTES, s, q);
+#if W6_TRACE
+    if (do_trace) {
+        ++traced;
+        long long h[256];
+        hipStreamSynchronize(s);
+        hipMemcpy(h, trace_dev, sizeof h, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "wino6 trace, block 40 wave %d, %d chunks: per item, cycles: K loop (per chunk) | dump 0 | barrier | rounds 0 | barrier + dump 1 | barrier | rounds 1 | item switch\n", 4 * w, nch);
+            for (int it = 0; it < 6; ++it) {
+                const long long *t = h + w * 128 + it * 16;
+                if (!t[0]) continue;
+                fprintf(stderr, "  item %d: %7lld (%5lld) | %5lld | %5lld | %5lld | %5lld | %5lld | %5lld | %5lld\n", it, t[1] - t[0], (t[1] - t[0]) / nch, t[2] - t[1], t[3] - t[2], t[4] - t[3],
+                        t[5] - t[4], t[6] - t[5], t[7] - t[6], t[8] - t[7]);
+            }
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
