@@ -666,6 +666,7 @@ bool wino6_supported(const ConvLaunch &p)
     if ((double)wino6_nblk(p.cout) * nchunks * wino6::UC >= 2147483648.0) return false;             // 32-bit scalar offsets into the weights
     for (int i = 0; i < p.nseg; ++i)        // signed 32-bit scalar chunk offsets of the buffer loads
         if ((double)p.seg[i].nchunks * (double)p.seg[i].chunk_stride * 4.0 + 9.0 * p.W * p.seg[0].pix_stride * 4.0 >= 2147483648.0) return false;
+    if ((double)((p.cout + 7) / 8) * (double)p.out_chunk_stride * 4.0 + (double)p.Ho * p.Wo * p.out_pix_stride * 4.0 >= 2147483648.0) return false;   // 31-bit store offsets (the range check drops anything beyond)
     return (double)p.H * p.W * p.seg[0].pix_stride * 4.0 < 2147483648.0;   // 32-bit byte offsets inside a plane
 }
 
