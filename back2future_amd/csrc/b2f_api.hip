@@ -880,6 +880,18 @@ int b2f_init_ex(const char *name_or_path, int device, const char *graph_opts, b2
         c->host_threads = (int)env_int("B2F_HOST_THREADS", c->host_threads);
         c->host_u8 = (int)env_int("B2F_HOST_U8", c->host_u8);
         c->host_ramp = (int)env_int("B2F_HOST_RAMP", c->host_ramp);
+#if !B2F_EXPERIMENTS
+        // the same rule b2f_set_option enforces: an experiment kernel that is not in this build is not accepted under its name (an A/B
+        // run driven by the environment would otherwise time the default kernel under another label); get_option reports what runs
+        if (c->corr_variant == 2 || c->corr_variant == 4 || c->corr_variant == 6 || c->corr_variant == 8) {
+            fprintf(stderr, "b2f_init: B2F_CORR_VARIANT=%d is an experiment kernel (build with `python -m back2future_amd.build --experiments`): using the default\n", c->corr_variant);
+            c->corr_variant = -1;
+        }
+        if (c->bf16_direct == 1) {
+            fprintf(stderr, "b2f_init: B2F_BF16_DIRECT=1 is an experiment (build with `python -m back2future_amd.build --experiments`): using the default (2)\n");
+            c->bf16_direct = 2;
+        }
+#endif
     }
     // a blocking stream: ordered with the legacy default stream like any such stream, so inputs that PyTorch (whose
     // default stream is the null stream) or hipMemcpy / hipMemset produced there are complete before our kernels read them

@@ -1105,8 +1105,9 @@ hipError_t launch_warp_costvol(const CorrLaunch &p_in, hipStream_t s)
 #if !B2F_EXPERIMENTS
     if (p.variant == 2 || p.variant == 4 || p.variant == 6 || p.variant == 8) p.variant = 3;     // experiment kernels (tools/experiments): not in this build
 #endif
+    const unsigned n_cu = (unsigned)device_cu_count(), round2 = 15 * n_cu / 4;   // 960 of the two-pixel kernel's 1 024 resident blocks on 256 CUs
     int variant = p.variant >= 0 ? (p.variant == 4 && !win_ok ? 3 : p.variant)
-                  : (p.ablate ? 0 : ((p.h * p.w <= 2048 || 2 * g2.x < 960) && warp_costvol_unit_supported(p)) ? 7 : 2 * g2.x >= 960 ? 3 : grid.x <= 512 ? 1 : 0);
+                  : (p.ablate ? 0 : ((p.h * p.w <= 2048 || 2 * g2.x < round2) && warp_costvol_unit_supported(p)) ? 7 : 2 * g2.x >= round2 ? 3 : grid.x <= 2u * n_cu ? 1 : 0);
     if ((variant == 5 || variant == 6 || variant == 7) && !warp_costvol_unit_supported(p)) variant = 3;
     if (variant == 5) return launch_warp_costvol_unit(p, s);
     if (variant == 7) return launch_warp_costvol_gw(p, s);

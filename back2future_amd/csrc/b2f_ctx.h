@@ -254,7 +254,7 @@ struct b2f_ctx {
     int wino6 = 1;                 // F(4x4)-class layers on maps of at least wino6_min_pixels pixels: 1 = Winograd F(6x6,3x3) on the fp32 MFMA (csrc/b2f_wino6.hip):
                                    // blocks of 64 outputs, a last block of 32 when the outputs are <= 32 mod 64
     int wino6_min_pixels = 16384;  // ... below that the F(4x4) kernel (items of 12 x 48 pixels quantise small maps badly)
-    int wino1d = 0;                // F(4x4)-class layers (stride 1, >= 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
+    int wino1d = 0;                // F(4x4)-class layers (stride 1, more than 32 outputs, maps of at least wino4_min_pixels pixels): 1 = one-dimensional
                                    // Winograd F(4,3) on the bf16 matrix pipe with exactly split fp32 operands, loader / consumer persistent blocks
                                    // (b2f_w1b.hip); 0 = the fp32-MFMA F(4x4) kernel of rounds 1-4 (b2f_wino4.hip)
     int s2_tile_groups = 1;        // ... launches that cannot fill the chip: one output tile per block (conv3x3_s2b<1, 1>, ConvLaunch::nsplit); same bits

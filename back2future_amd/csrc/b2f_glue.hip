@@ -411,7 +411,7 @@ hipError_t launch_conv_narrow2(const ConvLaunch &p, hipStream_t s)
 {
     if (p.stride != 1 || p.cout != 2 || p.nseg != 1 || (p.seg[0].pix_stride & 3) || (p.out_pix_stride & 1)) return hipErrorInvalidValue;
     const int tiles = ((p.W + 15) / 16) * ((p.H + 15) / 16);
-    if ((long)tiles * p.nimg <= 768 && p.seg[0].nchunks > 2)   // at most three blocks per CU anyway
+    if ((long)tiles * p.nimg <= 3L * device_cu_count() && p.seg[0].nchunks > 2)   // at most three blocks per CU anyway
         hipLaunchKernelGGL(conv_narrow2_kernel<4>, dim3((unsigned)(tiles * p.nimg)), dim3(256), 0, s, p.seg[0].ptr, p.seg[0].img_stride,
                            p.seg[0].chunk_stride, p.seg[0].pix_stride, p.seg[0].nchunks, p.H, p.W, p.wpk, p.bias, p.out,
                            p.out_img_stride, p.out_pix_stride, p.leaky);

@@ -214,6 +214,19 @@ inline int attr_slot()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     return dev & 63;
 }
+// compute units of the current device (cached per device; 256 on an MI355X in SPX mode, fewer in a partition mode): the launchers'
+// "does this launch fit in one round of blocks" thresholds scale with it
+inline int device_cu_count()
+{
+    static int n_cu_dev[64] = {0};
+    int &n = n_cu_dev[attr_slot()];
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v < 8 ? 8 : v;
+    }
+    return n;
+}
 #ifdef __HIPCC__
 // MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs (8 private L2s).  Give every XCD one
 // contiguous range of logical work items instead (bijective for any grid size; placement only affects speed).

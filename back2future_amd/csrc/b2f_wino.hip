@@ -626,18 +626,19 @@ hipError_t launch_conv3x3_wino(const ConvLaunch &p, hipStream_t s)
     // one-N-tile launches of at most one block per CU: the eight-wave form (same bits; p.w8 = 0 switches it off)
     const long tiles8 = (long)((p.Wo + wino::TW - 1) / wino::TW) * ((p.Ho + wino::TH - 1) / wino::TH) * p.nimg;
     const bool w8 = p.w8 != 0;
-    if (p.nt == 1) return (w8 && tiles8 * p.nblk <= 256) ? launch_wino8_t<1>(p, 0, p.nblk, s) : launch_wino_t<1, 1>(p, 0, p.nblk, s);
+    const long n_cu = device_cu_count();
+    if (p.nt == 1) return (w8 && tiles8 * p.nblk <= n_cu) ? launch_wino8_t<1>(p, 0, p.nblk, s) : launch_wino_t<1, 1>(p, 0, p.nblk, s);
     if (p.nt != 2) return hipErrorInvalidValue;
     if (p.nsplit) {   // one block per 32 outputs
         const int n32 = (p.cout + 31) / 32;
-        return (w8 && tiles8 * n32 <= 256) ? launch_wino8_t<2>(p, 0, n32, s) : launch_wino_t<2, 1>(p, 0, n32, s);
+        return (w8 && tiles8 * n32 <= n_cu) ? launch_wino8_t<2>(p, 0, n32, s) : launch_wino_t<2, 1>(p, 0, n32, s);
     }
     // n-blocks whose two N tiles both hold real channels, then the half-empty last one (cout = 96)
     const int nfull = p.cout / 64, part = (p.cout % 64) ? 1 : 0;
     const bool part_full = (p.cout % 64) > 32;
     hipError_t e = hipSuccess;
     if (nfull + (part_full ? 1 : 0) > 0) e = launch_wino_t<2, 2>(p, 0, nfull + (part_full ? 1 : 0), s);
-    if (e == hipSuccess && part && !part_full) e = (w8 && tiles8 <= 256) ? launch_wino8_t<2>(p, nfull, 1, s) : launch_wino_t<2, 1>(p, nfull, 1, s);
+    if (e == hipSuccess && part && !part_full) e = (w8 && tiles8 <= n_cu) ? launch_wino8_t<2>(p, nfull, 1, s) : launch_wino_t<2, 1>(p, nfull, 1, s);
     return e;
 }
 

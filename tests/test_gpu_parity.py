@@ -1114,6 +1114,26 @@ def test_direct_kernels_everywhere_end_to_end():
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_environment_cannot_name_a_kernel_that_is_not_in_the_build():
+    """B2F_<OPTION> seeds an option at b2f_init with the rule b2f_set_option enforces: an experiment kernel that the product build does not
+    hold (cost-volume variants 2/4/6/8, bf16_direct = 1) is not accepted under its name -- get_option reports what runs."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "from back2future_amd import back2future\n"
+        "m = back2future.Model('random:hard:5:2.0')\n"
+        "exp = m.get_option('experiments')\n"
+        "cv, bd = m.get_option('corr_variant'), m.get_option('bf16_direct')\n"
+        "assert (cv, bd) == ((4, 1) if exp else (-1, 2)), (exp, cv, bd)\n"
+        "assert m.get_option('wino6') == 0\n"
+        "print('ok')\n")
+    env = dict(os.environ, B2F_CORR_VARIANT="4", B2F_BF16_DIRECT="1", B2F_WINO6="0", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("B,ci,co,h,w,scale,blocks", [(1, 64, 96, 16, 64, 1.0, 1), (2, 32, 64, 37, 71, 1.0, 3), (1, 64, 96, 33, 50, 300.0, 1), (3, 96, 128, 9, 130, 1e-3, 2),
                                                       (1, 128, 192, 32, 60, 1.0, 1), (2, 40, 64, 20, 20, 1.0, 1), (1, 64, 100, 31, 33, 1.0, 7), (1, 24, 32, 40, 66, 1.0, 1),
                                                       (1, 8, 256, 2, 2, 1.0, 1), (4, 16, 36, 1, 1, 1.0, 1), (3, 72, 160, 64, 48, 1.0, 5), (1, 64, 96, 8, 16, 1.0, 2)])
