@@ -497,11 +497,13 @@ def main():
             a = d_alg / (d_ms * 1e-3) / 1e12
             ea = d_exe / (d_ms * 1e-3) / 1e12
             # `frac` is the utilisation of the matrix pipe: the FLOPs the MFMAs of this kernel really execute (Winograd
-            # F(4x4): 36/16 MACs per output and channel pair, channel padding included) / its time / the fp32 MFMA peak.
-            # The direct-convolution-equivalent rate (4x the MACs) is reported separately as `effective_vs_direct`.
+            # F(6x6): 64/36, F(4x4): 36/16 MACs per output and channel pair, channel padding included) / its time / the nominal
+            # fp32 MFMA peak.  The direct-convolution-equivalent rate (9 MACs) is reported separately as `effective_vs_direct`.
             out["roofline"] = {"kernel": "%s (Winograd %s on the fp32 MFMA; %.0f %% of the profiled step)" % (dom, "F(6x6,3x3)" if dom == "conv3x3_wino6" else "F(4x4,3x3)", 100.0 * d_ms / (1e3 * prof_dt / args.steps))
                                if dom in ("conv3x3_wino4", "conv3x3_wino6") else dom,
                                "bound": "mfma", "achieved": ea, "peak": 157.3, "unit": "TFLOP/s", "frac": ea / 157.3,
+                               "peak_note": "nominal dense fp32 matrix peak at 2.4 GHz (MI355X_MICROARCH.md); `frac` is a fraction OF NOMINAL -- "
+                                            "under the Winograd kernels the chip holds 2.07 - 2.1 GHz (profiles/r06_wino6_notes.txt)",
                                "executed_flop_per_step": d_exe,
                                "effective_vs_direct": {"achieved": a, "unit": "TFLOP/s of direct-convolution FLOPs (2*9*Ci*Co per output)",
                                                        "x_peak": a / 157.3, "algorithmic_flop_per_step": d_alg},
