@@ -73,8 +73,8 @@ def test_baseline_config_full_size(which, B, H, Wd):
         assert d.max() <= 1e-3 and epe <= 1e-3, (d.max(), epe)
         assert np.abs(occ[i].cpu().numpy() - eocc).max() <= 1e-3
         # ... and far inside the contract's bar with these weights: the Winograd kernels' fp32 rounding (F(6x6) on the large maps, F(4x4) and
-        # F(2x2) below) leaves the flow within 2e-5 of the oracle's
-        assert d.max() <= 2e-5, d.max()
+        # F(2x2) below) leaves the flow within 1e-5 of the oracle's (measured: 1e-7, profiles/r06_e2e_error.txt)
+        assert d.max() <= 1e-5, d.max()
         # the host-buffer boundary on the same triplet: same network outputs behind computeFlow's post-processing
         ims = [np.ascontiguousarray(x[i, 3 * f:3 * f + 3].cpu().numpy()) for f in range(3)]
         cflow, fo, bo = m.computeFlow(*ims)
