@@ -69,7 +69,8 @@ __device__ __host__ constexpr int cj(int j) { return j < 6 ? 9 * j : 9 * (j - 6)
 }  // namespace wino6
 
 // Profiling only (results are wrong): -DW6_ABLATE=bits, 1 no input transform, 2 no raw staging, 4 no weight loads, 8 no MFMAs, 16 no period barrier,
-// 32 no output rounds (reads, transform, stores), 64 no in-register output transform + dump, 128 every item loads the same patch (L2-resident)
+// 32 no output rounds (reads, transform, stores), 64 no in-register output transform + dump, 128 every item loads the same patch (L2-resident),
+// 256 every output store dropped by the buffer range check, 512 every item of a block stores to its first item's place (L2-resident stores)
 #ifndef W6_ABLATE
 #define W6_ABLATE 0
 #endif
@@ -244,7 +245,7 @@ __device__ __forceinline__ void wino6_output(wino6::f32x4 (&acc)[8][NT], char *s
             }
             const int oy = oy0 + 6 * tyy + par, ox = ox0 + x;
             const unsigned ooff = (unsigned)(((size_t)(co0 >> 3) * p.out_chunk_stride + (size_t)(oy * p.Wo + ox) * p.out_pix_stride + (co0 & 7)) * 4);
-            const bool ok = co0 < p.cout && ox < p.Wo;
+            const bool ok = !(W6_ABLATE & 256) && co0 < p.cout && ox < p.Wo;            // (ablation 256: every store dropped by the range check)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 // LeakyReLU(0.2) = max(v, 0.2 v) (slope 1: identity): two packed multiplies, four plain maxima as asm (fmaxf() costs a second
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
         bo_c = bo_n;                                                                                \
         if (++c == nchunks) {                                                                       \
             W6_T(1);                                                                                \
-            wino6_output<NT>(acc, smem, p, tid, lane, wave, cur_nb, cur_img, cur_ox0, cur_oy0, tr_on, tr_item, tr_buf); \
+            if (W6_ABLATE & 512) wino6_output<NT>(acc, smem, p, tid, lane, wave, cur_nb, first_img, first_ox0, first_oy0, tr_on, tr_item, tr_buf); /* (timing: every item of a block stores to its first item's place -- L2-resident) */ \
+            else wino6_output<NT>(acc, smem, p, tid, lane, wave, cur_nb, cur_img, cur_ox0, cur_oy0, tr_on, tr_item, tr_buf); \
             if (!has_next) { more = false; }                                                        \
             else {                                                                                  \
                 v_cur += G;                                                                         \
@@ -630,6 +632,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(const ConvLaunch p)
             }                                                                                       \
         }                                                                                           \
     } while (0)
+    const int first_img = cur_img, first_ox0 = cur_ox0, first_oy0 = cur_oy0;
     W6_ITEM_START();
     W6_T(0);
     while (more) {
