@@ -2,7 +2,7 @@
 context (so the workspace arena, the graph cache and the per-shape plans keep changing), on torch's current stream or
 a side stream, eager or graph replay; every pass is checked against the same triplets computed one at a time, and
 now and then against a fresh context and the full-table entry point.
-    python tools/soak_device.py [iterations] [seed]
+    python tools/soak_device.py [iterations] [seed] [big]
 """
 import os
 import sys
@@ -32,10 +32,13 @@ def run(m, x, stream=None, unit=True):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"   # every fourth pass at 384..704 x 512..1024
     r = np.random.default_rng(seed)
     os.environ["B2F_WINO4_MIN_PIXELS"] = "4096"      # kernel choice independent of the batch: bit-identical results
     g = torch.Generator(device="cuda").manual_seed(seed)
     models = {"hard": back2future.Model("random:hard:3:2.0"), "soft": back2future.Model("random:soft:3:2.0")}
+    for m in models.values():
+        m.set_option("adaptive_kernels", 0)          # kernel choice by map size also for the single-triplet reference passes (the default -1 picks per launch there: 1e-6-level differences)
     side = torch.cuda.Stream()
     t0 = time.time()
     for it in range(iters):
@@ -43,6 +46,7 @@ def main():
         m = models[which]
         B = int(r.integers(1, 7))
         H, W = 64 * int(r.integers(1, 6)), 64 * int(r.integers(1, 8))
+        if big and it % 4 == 0: H, W = 64 * int(r.integers(6, 12)), 64 * int(r.integers(8, 17))   # level-3 maps of >= 16 384 pixels: the F(6x6) kernel
         m_graph = int(r.integers(2))
         m.set_option("use_graph", m_graph)
         stream = side if r.integers(2) else None
